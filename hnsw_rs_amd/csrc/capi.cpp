@@ -1,0 +1,569 @@
+// capi.cpp -- the extern "C" surface of libhnsw_mi355x.so (include/hnsw_mi355x.h).
+// Host logic only; the search entry points upload the index snapshot to HBM on demand and
+// launch the HIP kernels of search_kernels.hip.  There is no CPU search path.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "device_index.h"
+#include "host_index.h"
+
+using hx::set_error;
+
+struct hnsw_index {
+    std::unique_ptr<hx::HostIndex> host;
+    hx::DeviceIndex dev;
+    int device = -1;
+    std::mutex mu;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                                                         \
+    do {                                                                      \
+        hipError_t e_ = (expr);                                               \
+        if (e_ != hipSuccess) {                                               \
+            set_error("%s failed: %s", #expr, hipGetErrorString(e_));         \
+            return e_ == hipErrorOutOfMemory ? HNSW_ERR_OOM : HNSW_ERR_HIP;   \
+        }                                                                     \
+    } while (0)
+
+struct DevBuf {  // RAII device allocation
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t n) {
+        HIP_TRY(hipMalloc(&p, n ? n : 1));
+        return HNSW_OK;
+    }
+    template <class T>
+    T *as() {
+        return static_cast<T *>(p);
+    }
+};
+
+int ensure_uploaded(hnsw_index *h) {
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->dev.current(*h->host)) {
+        int rc = h->dev.upload(*h->host, h->device);
+        if (rc != HNSW_OK) return rc;
+        h->device = h->dev.device;
+    }
+    hipError_t e = hipSetDevice(h->dev.device);
+    if (e != hipSuccess) {
+        set_error("hipSetDevice(%d): %s", h->dev.device, hipGetErrorString(e));
+        return HNSW_ERR_HIP;
+    }
+    return HNSW_OK;
+}
+
+int check_search_args(const hnsw_index *h, uint32_t ef) {
+    if (!h) {
+        set_error("null handle");
+        return HNSW_ERR_ARG;
+    }
+    if (h->host->len() == 0) {
+        set_error("index is empty");
+        return HNSW_ERR_EMPTY;
+    }
+    if (ef > 64 * 8) {
+        set_error("ef = %u is above the supported maximum of 512", ef);
+        return HNSW_ERR_ARG;
+    }
+    return HNSW_OK;
+}
+
+hx::SearchArgs ann_args(const hx::DevView &v, const float *dQ, uint32_t n, uint32_t ef,
+                        uint32_t *ids, float *dists, uint32_t *counts, hnsw_query_stats *stats) {
+    hx::SearchArgs a{};
+    a.Q = dQ;
+    a.qsel = nullptr;
+    a.entries = nullptr;
+    a.n_entry = 1;
+    a.layer_hi = (int32_t)v.nb_layers - 1;  // template.rs:322-326: layers L-1..1 with ef = 1,
+    a.layer_lo = 0;                         // then layer 0 with ef
+    a.ef_upper = 1;
+    a.ef_bottom = ef;
+    a.n = n;
+    a.out_ids = ids;
+    a.out_dists = dists;
+    a.out_counts = counts;
+    a.out_stats = stats;
+    return a;
+}
+
+// host-pointer search with the overflow retry: queries whose visited table filled up are run
+// again with a table twice the size
+int search_host(hnsw_index *h, hx::SearchArgs a_host, const float *Q, uint64_t nq, uint32_t *ids,
+                float *dists, uint32_t *counts, hnsw_query_stats *stats, const uint32_t *entries) {
+    int rc = ensure_uploaded(h);
+    if (rc != HNSW_OK) return rc;
+    const hx::DevView &v = h->dev.view;
+    const uint32_t n = a_host.n, d = v.dim;
+    DevBuf dQ, dIds, dDists, dCounts, dStats, dSel, dEnt;
+    if ((rc = dQ.alloc(nq * d * 4)) || (rc = dIds.alloc(nq * n * 4)) ||
+        (rc = dDists.alloc(nq * n * 4)) || (rc = dCounts.alloc(nq * 4)) ||
+        (rc = dStats.alloc(nq * sizeof(hnsw_query_stats))) || (rc = dSel.alloc(nq * 4)))
+        return rc;
+    HIP_TRY(hipMemcpy(dQ.p, Q, nq * d * 4, hipMemcpyHostToDevice));
+    hx::SearchArgs a = a_host;
+    a.Q = dQ.as<float>();
+    a.out_ids = dIds.as<uint32_t>();
+    a.out_dists = dDists.as<float>();
+    a.out_counts = dCounts.as<uint32_t>();
+    a.out_stats = dStats.as<hnsw_query_stats>();
+    if (entries) {
+        if ((rc = dEnt.alloc((size_t)a.n_entry * 4))) return rc;
+        HIP_TRY(hipMemcpy(dEnt.p, entries, (size_t)a.n_entry * 4, hipMemcpyHostToDevice));
+        a.entries = dEnt.as<uint32_t>();
+    }
+    std::vector<hnsw_query_stats> st(nq);
+    uint32_t ef_max = std::max(a.ef_bottom, a.ef_upper);
+    uint32_t slots = hx::default_slots_log2(ef_max);
+    uint64_t nrun = nq;
+    std::vector<uint32_t> sel;
+    while (true) {
+        rc = hx::launch_search(v, a, (uint32_t)nrun, slots, nullptr);
+        if (rc != HNSW_OK) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(st.data(), dStats.p, nq * sizeof(hnsw_query_stats), hipMemcpyDeviceToHost));
+        sel.clear();
+        for (uint64_t i = 0; i < nq; i++)
+            if (st[i].status == HNSW_ERR_OVERFLOW) sel.push_back((uint32_t)i);
+        if (sel.empty() || slots >= hx::max_slots_log2(ef_max)) break;
+        slots++;
+        HIP_TRY(hipMemcpy(dSel.p, sel.data(), sel.size() * 4, hipMemcpyHostToDevice));
+        a.qsel = dSel.as<uint32_t>();
+        nrun = sel.size();
+    }
+    HIP_TRY(hipMemcpy(ids, dIds.p, nq * n * 4, hipMemcpyDeviceToHost));
+    if (dists) HIP_TRY(hipMemcpy(dists, dDists.p, nq * n * 4, hipMemcpyDeviceToHost));
+    if (counts) HIP_TRY(hipMemcpy(counts, dCounts.p, nq * 4, hipMemcpyDeviceToHost));
+    if (stats) memcpy(stats, st.data(), nq * sizeof(hnsw_query_stats));
+    for (uint64_t i = 0; i < nq; i++) {
+        if (st[i].status != HNSW_OK) {
+            switch (st[i].status) {
+                case HNSW_ERR_NAN_INPUT:
+                    set_error("query %llu: NaN in the query or in a distance", (unsigned long long)i);
+                    break;
+                case HNSW_ERR_NODE_NOT_IN_GRAPH:
+                    set_error("Error in search_layer: node not in Graph (query %llu)",
+                              (unsigned long long)i);
+                    break;
+                case HNSW_ERR_OVERFLOW:
+                    set_error("query %llu: visited table exhausted at its largest size",
+                              (unsigned long long)i);
+                    break;
+                default:
+                    set_error("query %llu failed with status %d", (unsigned long long)i, st[i].status);
+            }
+            return st[i].status;
+        }
+    }
+    return HNSW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *hnsw_last_error(void) { return hx::get_error(); }
+const char *hnsw_version(void) { return "hnsw_mi355x 0.1 (gfx950)"; }
+
+int hnsw_create(uint32_t m, uint32_t ef_cons, uint32_t dim, int vec_kind, hnsw_index **out) {
+    if (!out || m < 2 || dim == 0 || (vec_kind != HNSW_VEC_QUANT8 && vec_kind != HNSW_VEC_F32)) {
+        set_error("hnsw_create: need m >= 2, dim >= 1 and a valid vector kind");
+        return HNSW_ERR_ARG;
+    }
+    hnsw_index *h = new (std::nothrow) hnsw_index();
+    if (!h) return HNSW_ERR_OOM;
+    h->host.reset(new hx::HostIndex(m, ef_cons, dim, vec_kind));
+    *out = h;
+    return HNSW_OK;
+}
+
+void hnsw_free(hnsw_index *h) { delete h; }
+
+int hnsw_clone(const hnsw_index *h, hnsw_index **out) {
+    if (!h || !out) return HNSW_ERR_ARG;
+    hnsw_index *c = new (std::nothrow) hnsw_index();
+    if (!c) return HNSW_ERR_OOM;
+    c->host.reset(new hx::HostIndex(*h->host));
+    c->device = h->device;
+    *out = c;
+    return HNSW_OK;
+}
+
+int hnsw_get_params(const hnsw_index *h, hnsw_params *out) {
+    if (!h || !out) return HNSW_ERR_ARG;
+    const hx::Params &p = h->host->params;
+    memset(out, 0, sizeof(*out));
+    out->ep = p.ep;
+    out->vec_kind = (uint32_t)h->host->kind;
+    out->m = p.m;
+    out->mmax = p.mmax;
+    out->mmax0 = p.mmax0;
+    out->ml = p.ml;
+    out->ef_cons = p.ef_cons;
+    out->dim = p.dim;
+    return HNSW_OK;
+}
+
+int hnsw_set_ep(hnsw_index *h, uint32_t ep) {
+    if (!h || ep >= h->host->len()) {
+        set_error("entry point %u out of range", ep);
+        return HNSW_ERR_ARG;
+    }
+    h->host->params.ep = ep;
+    h->host->version++;
+    return HNSW_OK;
+}
+
+int hnsw_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads, int verbose) {
+    return hnsw_insert_bulk_levels(h, rows, n, nb_threads, verbose, nullptr);
+}
+int hnsw_insert_bulk_levels(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads,
+                            int verbose, const uint8_t *levels) {
+    if (!h || !rows) return HNSW_ERR_ARG;
+    return h->host->insert_bulk(rows, n, nb_threads, verbose != 0, levels);
+}
+int hnsw_insert_vec(hnsw_index *h, const float *v, uint32_t *out_id) {
+    return hnsw_insert_vec_level(h, v, -1, out_id);
+}
+int hnsw_insert_vec_level(hnsw_index *h, const float *v, int level, uint32_t *out_id) {
+    if (!h || !v || level > 255) return HNSW_ERR_ARG;
+    return h->host->insert_vec(v, level, out_id);
+}
+int hnsw_import_points(hnsw_index *h, const float *rows, uint64_t n, const uint8_t *levels) {
+    if (!h || !rows) return HNSW_ERR_ARG;
+    return h->host->import_points(rows, n, levels);
+}
+int hnsw_import_layer(hnsw_index *h, uint32_t layer, uint64_t n_nodes, const uint32_t *node_ids,
+                      const uint64_t *offsets, const uint32_t *nbrs) {
+    if (!h || !node_ids || !offsets) return HNSW_ERR_ARG;
+    return h->host->import_layer(layer, n_nodes, node_ids, offsets, nbrs);
+}
+
+// ---- query -------------------------------------------------------------------------------------
+int hnsw_search(hnsw_index *h, const float *q, uint32_t n, uint32_t ef, uint32_t *ids,
+                uint32_t *count) {
+    return hnsw_search_batch(h, q, 1, n, ef, ids, nullptr, count, nullptr);
+}
+
+int hnsw_search_batch(hnsw_index *h, const float *Q, uint64_t nq, uint32_t n, uint32_t ef,
+                      uint32_t *ids, float *dists, uint32_t *counts, hnsw_query_stats *stats) {
+    int rc = check_search_args(h, ef);
+    if (rc != HNSW_OK) return rc;
+    if (nq == 0) return HNSW_OK;
+    if (!Q || !ids || nq > 0x7FFFFFFFull) return HNSW_ERR_ARG;
+    if (n == 0) {
+        if (counts) memset(counts, 0, nq * 4);
+        return HNSW_OK;
+    }
+    hx::DevView dummy{};
+    dummy.nb_layers = h->host->nb_layers();
+    hx::SearchArgs a = ann_args(dummy, nullptr, n, ef, nullptr, nullptr, nullptr, nullptr);
+    return search_host(h, a, Q, nq, ids, dists, counts, stats, nullptr);
+}
+
+int hnsw_search_batch_device(hnsw_index *h, const float *d_Q, uint64_t nq, uint32_t n, uint32_t ef,
+                             uint32_t *d_ids, float *d_dists, uint32_t *d_counts,
+                             hnsw_query_stats *d_stats, void *stream) {
+    int rc = check_search_args(h, ef);
+    if (rc != HNSW_OK) return rc;
+    if (nq == 0 || n == 0) return HNSW_OK;
+    if (!d_Q || !d_ids || !d_stats || nq > 0x7FFFFFFFull) return HNSW_ERR_ARG;
+    rc = ensure_uploaded(h);
+    if (rc != HNSW_OK) return rc;
+    hx::SearchArgs a = ann_args(h->dev.view, d_Q, n, ef, d_ids, d_dists, d_counts, d_stats);
+    return hx::launch_search(h->dev.view, a, (uint32_t)nq, 0, static_cast<hipStream_t>(stream));
+}
+
+int hnsw_distance_batch(hnsw_index *h, const float *q, const uint32_t *ids, uint64_t k, float *out) {
+    int rc = check_search_args(h, 1);
+    if (rc != HNSW_OK) return rc;
+    if (k == 0) return HNSW_OK;
+    if (!q || !ids || !out) return HNSW_ERR_ARG;
+    rc = ensure_uploaded(h);
+    if (rc != HNSW_OK) return rc;
+    const hx::DevView &v = h->dev.view;
+    DevBuf dq, dids, dout, dst;
+    if ((rc = dq.alloc(v.dim * 4)) || (rc = dids.alloc(k * 4)) || (rc = dout.alloc(k * 4)) ||
+        (rc = dst.alloc(4)))
+        return rc;
+    HIP_TRY(hipMemcpy(dq.p, q, v.dim * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dids.p, ids, k * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dst.p, 0, 4));
+    rc = hx::launch_distance_batch(v, dq.as<float>(), dids.as<uint32_t>(), k, dout.as<float>(),
+                                   dst.as<int32_t>(), nullptr);
+    if (rc != HNSW_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    int32_t st = 0;
+    HIP_TRY(hipMemcpy(&st, dst.p, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, dout.p, k * 4, hipMemcpyDeviceToHost));
+    if (st != HNSW_OK) {
+        set_error(st == HNSW_ERR_NAN_INPUT ? "NaN in the query" : "point id out of range");
+        return st;
+    }
+    return HNSW_OK;
+}
+
+int hnsw_search_layer(hnsw_index *h, uint32_t layer, const float *q, const uint32_t *entry_ids,
+                      uint32_t n_entry, uint32_t ef, uint32_t *out_ids, float *out_dists,
+                      uint32_t *out_count, hnsw_query_stats *stats) {
+    int rc = check_search_args(h, ef);
+    if (rc != HNSW_OK) return rc;
+    if (!q || !entry_ids || !out_ids || !out_count || n_entry == 0 || ef == 0) return HNSW_ERR_ARG;
+    if (layer >= h->host->nb_layers()) {
+        set_error("Layer %u not found in the structure.", layer);  // layers.rs:25-30 panics
+        return HNSW_ERR_ARG;
+    }
+    if (n_entry > ef) {
+        set_error("search_layer seam: the entry set (%u) may not be larger than ef (%u)", n_entry, ef);
+        return HNSW_ERR_ARG;
+    }
+    for (uint32_t i = 0; i < n_entry; i++) {
+        if (!h->host->in_layer(layer, entry_ids[i])) {
+            set_error("entry %u is not in layer %u", entry_ids[i], layer);
+            return HNSW_ERR_NODE_NOT_IN_GRAPH;
+        }
+        for (uint32_t j = 0; j < i; j++)
+            if (entry_ids[j] == entry_ids[i]) {
+                set_error("duplicate entry %u", entry_ids[i]);
+                return HNSW_ERR_ARG;
+            }
+    }
+    hx::SearchArgs a{};
+    a.n_entry = n_entry;
+    a.layer_hi = a.layer_lo = (int32_t)layer;
+    a.ef_upper = 1;
+    a.ef_bottom = ef;
+    a.n = ef;
+    std::vector<uint32_t> ids(ef);
+    std::vector<float> dists(ef);
+    uint32_t count = 0;
+    hnsw_query_stats st{};
+    rc = search_host(h, a, q, 1, ids.data(), dists.data(), &count, &st, entry_ids);
+    if (rc != HNSW_OK) return rc;
+    for (uint32_t i = 0; i < count; i++) {
+        out_ids[i] = ids[i];
+        if (out_dists) out_dists[i] = dists[i];
+    }
+    *out_count = count;
+    if (stats) *stats = st;
+    return HNSW_OK;
+}
+
+int hnsw_brute_force(hnsw_index *h, const float *Q, uint64_t nq, uint32_t k, uint32_t *ids,
+                     float *dists) {
+    int rc = check_search_args(h, 1);
+    if (rc != HNSW_OK) return rc;
+    if (nq == 0) return HNSW_OK;
+    if (!Q || !ids || k == 0 || k > 64) {
+        set_error("brute force supports 1 <= k <= 64");
+        return HNSW_ERR_ARG;
+    }
+    rc = ensure_uploaded(h);
+    if (rc != HNSW_OK) return rc;
+    const hx::DevView &v = h->dev.view;
+    const uint32_t nseg = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(512, (v.n_points + 2047) / 2048));
+    const uint64_t batch = 2048;
+    DevBuf dQ, dIds, dDists, dSt;
+    if ((rc = dQ.alloc(batch * v.dim * 4)) || (rc = dIds.alloc(batch * nseg * k * 4)) ||
+        (rc = dDists.alloc(batch * nseg * k * 4)) || (rc = dSt.alloc(4)))
+        return rc;
+    std::vector<uint32_t> pid(batch * nseg * k);
+    std::vector<float> pd(batch * nseg * k);
+    std::vector<std::pair<float, uint32_t>> cand;
+    for (uint64_t q0 = 0; q0 < nq; q0 += batch) {
+        const uint64_t nb = std::min(batch, nq - q0);
+        HIP_TRY(hipMemcpy(dQ.p, Q + q0 * v.dim, nb * v.dim * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(dSt.p, 0, 4));
+        rc = hx::launch_brute_force(v, dQ.as<float>(), nb, k, nseg, dIds.as<uint32_t>(),
+                                    dDists.as<float>(), dSt.as<int32_t>(), nullptr);
+        if (rc != HNSW_OK) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        int32_t st = 0;
+        HIP_TRY(hipMemcpy(&st, dSt.p, 4, hipMemcpyDeviceToHost));
+        if (st != HNSW_OK) {
+            set_error("NaN in a query or a distance");
+            return st;
+        }
+        HIP_TRY(hipMemcpy(pid.data(), dIds.p, nb * nseg * k * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(pd.data(), dDists.p, nb * nseg * k * 4, hipMemcpyDeviceToHost));
+        for (uint64_t qi = 0; qi < nb; qi++) {
+            cand.clear();
+            for (uint64_t j = 0; j < (uint64_t)nseg * k; j++) {
+                const uint32_t id = pid[qi * nseg * k + j];
+                if (id != UINT32_MAX) cand.emplace_back(pd[qi * nseg * k + j], id);
+            }
+            std::sort(cand.begin(), cand.end());  // (dist, id): Dist::cmp for non-NaN distances
+            for (uint32_t j = 0; j < k; j++) {
+                const bool have = j < cand.size();
+                ids[(q0 + qi) * k + j] = have ? cand[j].second : UINT32_MAX;
+                if (dists) dists[(q0 + qi) * k + j] = have ? cand[j].first : INFINITY;
+            }
+        }
+    }
+    return HNSW_OK;
+}
+
+// ---- accessors -----------------------------------------------------------------------------------
+uint64_t hnsw_len(const hnsw_index *h) { return h ? h->host->len() : 0; }
+
+int hnsw_distance(const hnsw_index *h, uint32_t a, uint32_t b, float *out) {
+    if (!h || !out) return HNSW_ERR_ARG;
+    hx::PointView pa, pb;
+    if (!h->host->get_point(a, &pa) || !h->host->get_point(b, &pb)) return HNSW_ERR_ARG;  // None
+    *out = h->host->dist2other(pa, pb);
+    return HNSW_OK;
+}
+
+int hnsw_get_vector(const hnsw_index *h, uint32_t id, float *out) {
+    if (!h || !out) return HNSW_ERR_ARG;
+    hx::PointView p;
+    if (!h->host->get_point(id, &p)) return HNSW_ERR_ARG;
+    const uint32_t d = h->host->dim;
+    if (h->host->kind == HNSW_VEC_QUANT8)
+        for (uint32_t i = 0; i < d; i++) out[i] = ((float)p.codes[i] * p.delta) + p.min;  // quant.rs:79-83
+    else
+        memcpy(out, p.vals, 4 * (size_t)d);
+    return HNSW_OK;
+}
+
+int hnsw_get_level(const hnsw_index *h, uint32_t id, uint32_t *out) {
+    if (!h || !out || id >= h->host->len()) return HNSW_ERR_ARG;
+    *out = h->host->levels[id];
+    return HNSW_OK;
+}
+
+int hnsw_get_quant(const hnsw_index *h, uint32_t id, uint8_t *codes, float *min_out, float *delta_out) {
+    if (!h || h->host->kind != HNSW_VEC_QUANT8 || id >= h->host->len()) return HNSW_ERR_ARG;
+    if (codes) memcpy(codes, &h->host->codes[(size_t)id * h->host->dim], h->host->dim);
+    if (min_out) *min_out = h->host->mins[id];
+    if (delta_out) *delta_out = h->host->deltas[id];
+    return HNSW_OK;
+}
+
+uint32_t hnsw_layer_count(const hnsw_index *h) { return h ? h->host->nb_layers() : 0; }
+uint64_t hnsw_layer_nb_nodes(const hnsw_index *h, uint32_t layer) {
+    return (h && layer < h->host->nb_layers()) ? h->host->layer_nodes[layer].size() : 0;
+}
+uint32_t hnsw_layer_m(const hnsw_index *h, uint32_t layer) {
+    return (h && layer < h->host->nb_layers()) ? (uint32_t)h->host->layer_m(layer) : 0;
+}
+
+int hnsw_layer_nodes(const hnsw_index *h, uint32_t layer, uint32_t *out, uint64_t cap, uint64_t *n) {
+    if (!h || layer >= h->host->nb_layers()) return HNSW_ERR_ARG;
+    const std::vector<hx::NodeID> &ids = h->host->layer_nodes[layer];
+    if (n) *n = ids.size();
+    if (out)
+        for (uint64_t i = 0; i < ids.size() && i < cap; i++) out[i] = ids[i];
+    return HNSW_OK;
+}
+
+int hnsw_neighbors(const hnsw_index *h, uint32_t layer, uint32_t id, uint32_t *buf, uint32_t cap,
+                   uint32_t *deg) {
+    if (!h) return HNSW_ERR_ARG;
+    if (!h->host->in_layer(layer, id)) {
+        set_error("node %u not in graph (layer %u)", id, layer);
+        return HNSW_ERR_NODE_NOT_IN_GRAPH;
+    }
+    std::vector<hx::NodeID> nb = h->host->row(layer, id);
+    std::sort(nb.begin(), nb.end());
+    if (deg) *deg = (uint32_t)nb.size();
+    if (buf)
+        for (uint32_t i = 0; i < nb.size() && i < cap; i++) buf[i] = nb[i];
+    return HNSW_OK;
+}
+
+int hnsw_export_layer(const hnsw_index *h, uint32_t layer, uint32_t *node_ids, uint64_t *offsets,
+                      uint32_t *nbrs, uint64_t *n_nodes, uint64_t *nnz) {
+    if (!h || layer >= h->host->nb_layers()) return HNSW_ERR_ARG;
+    const std::vector<hx::NodeID> &ids = h->host->layer_nodes[layer];
+    uint64_t total = 0;
+    for (hx::NodeID id : ids) total += h->host->row(layer, id).size();
+    if (n_nodes) *n_nodes = ids.size();
+    if (nnz) *nnz = total;
+    if (!node_ids || !offsets || !nbrs) return HNSW_OK;
+    uint64_t off = 0;
+    for (uint64_t i = 0; i < ids.size(); i++) {
+        node_ids[i] = ids[i];
+        offsets[i] = off;
+        const std::vector<hx::NodeID> &r = h->host->row(layer, ids[i]);
+        std::copy(r.begin(), r.end(), nbrs + off);
+        std::sort(nbrs + off, nbrs + off + r.size());
+        off += r.size();
+    }
+    offsets[ids.size()] = off;
+    return HNSW_OK;
+}
+
+int hnsw_check_param_compliance(const hnsw_index *h, int *ok) {
+    if (!h || !ok) return HNSW_ERR_ARG;
+    *ok = h->host->check_param_compliance() ? 1 : 0;
+    return HNSW_OK;
+}
+
+// ---- persistence -----------------------------------------------------------------------------------
+int hnsw_save(const hnsw_index *h, const char *dir) {
+    if (!h || !dir) return HNSW_ERR_ARG;
+    return hx::save_index(*h->host, dir);
+}
+int hnsw_load(const char *dir, hnsw_index **out) {
+    if (!dir || !out) return HNSW_ERR_ARG;
+    std::unique_ptr<hx::HostIndex> idx;
+    int rc = hx::load_index(dir, &idx);
+    if (rc != HNSW_OK) return rc;
+    hnsw_index *h = new (std::nothrow) hnsw_index();
+    if (!h) return HNSW_ERR_OOM;
+    h->host = std::move(idx);
+    *out = h;
+    return HNSW_OK;
+}
+
+// ---- device management -------------------------------------------------------------------------------
+int hnsw_device_count(int *count) {
+    if (!count) return HNSW_ERR_ARG;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    *count = c;
+    return HNSW_OK;
+}
+int hnsw_set_device(hnsw_index *h, int device) {
+    if (!h) return HNSW_ERR_ARG;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (device != h->device) h->dev.release();
+    h->device = device;
+    return HNSW_OK;
+}
+int hnsw_upload(hnsw_index *h) {
+    if (!h) return HNSW_ERR_ARG;
+    return ensure_uploaded(h);
+}
+int hnsw_device_bytes(const hnsw_index *h, uint64_t *bytes) {
+    if (!h || !bytes) return HNSW_ERR_ARG;
+    *bytes = h->dev.valid ? h->dev.bytes : 0;
+    return HNSW_OK;
+}
+
+// ---- harness helpers -----------------------------------------------------------------------------------
+int hnsw_synth_rows(int recipe, uint64_t seed, uint64_t first_row, uint64_t n, uint32_t d, float *out,
+                    uint32_t nb_threads) {
+    if (!out) return HNSW_ERR_ARG;
+    return hx::synth_rows(recipe, seed, first_row, n, d, out, nb_threads);
+}
+int hnsw_draw_levels(uint32_t m, uint64_t n, uint8_t *out) {
+    if (!out || m < 2) return HNSW_ERR_ARG;
+    hx::stdrng_levels(0, hx::default_ml(m), n, out);
+    return HNSW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// device_index.h -- the HBM-resident snapshot of a HostIndex and the launchers of the search
+// kernels (search_kernels.hip).  gfx950 only.
+//
+// HBM layout (one allocation per array, all read-only during search):
+//
+//   rows      N x row_stride bytes.
+//             QUANT8 (reference QuantVec, vectors/src/quant.rs:6-11): a row is two halves of
+//             half_bytes each; half h (0/1) belongs to lane h of the lane pair that evaluates the
+//             row and holds [min f32][delta f32][the 4 codes (8c+4h .. 8c+4h+3) of every full
+//             8-chunk c, in chunk order][h == 0 only: the d % 8 tail codes][zero pad to 16 B].
+//             Lane h therefore streams its four running sums of distance_unrolled
+//             (quant.rs:14-37: sum j takes elements 8c + j) from contiguous 16-byte pieces.
+//             d = 100: half = 8 + 48 + 4 -> 64 B, row = 128 B = one cache line.
+//             F32 (reference FullVec, vectors/src/full.rs): d floats, padded to 16 B.
+//   adj0      N x S0 u32: layer-0 adjacency in fixed-stride rows (S0 = pow2 >= 2m, 128 B at
+//             m = 16), row index = node id, neighbour ids ascending, empty slots 0xFFFFFFFF.
+//   adj_up    upper-layer rows, S1 = pow2 >= max(m, 8) slots each; the rows of one node for
+//             layers 1..level are contiguous: row(id, l) = upper_base[id] + l - 1.
+//   upper_base N u32 (0xFFFFFFFF for level-0 nodes).
+//   ovf_off / ovf_nbrs  CSR of the neighbours that do not fit a row (degree > S happens:
+//             SURVEY.md H6).  Such a row keeps S - 1 ids and its last slot holds
+//             0x80000000 | overflow row.  Node ids are < 2^31 (enforced by the host index).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "host_index.h"
+
+namespace hx {
+
+#define HX_EMPTY_SLOT 0xFFFFFFFFu
+#define HX_OVF_FLAG 0x80000000u
+
+struct DevView {  // kernel argument, passed by value
+    const uint8_t *rows;
+    const uint32_t *adj0;
+    const uint32_t *adj_up;
+    const uint32_t *upper_base;
+    const uint32_t *ovf_off;
+    const uint32_t *ovf_nbrs;
+    uint32_t row_stride;  // bytes
+    uint32_t half_bytes;  // QUANT8: bytes per half row
+    uint32_t S0, S1;      // slots per adjacency row (powers of two)
+    uint32_t n_points, dim;
+    uint32_t nch4, rem;   // QUANT8: 4 * (dim / 8), dim % 8
+    uint32_t nb_layers, ep;
+    int32_t kind;
+    uint32_t _pad;
+};
+
+struct SearchArgs {
+    const float *Q;           // nq x dim (device)
+    const uint32_t *qsel;     // optional: launch block b serves query qsel[b]
+    const uint32_t *entries;  // optional explicit entry set (search_layer seam), else {ep}
+    uint32_t n_entry;
+    int32_t layer_hi, layer_lo;  // layers traversed: hi .. lo (inclusive, descending)
+    uint32_t ef_upper, ef_bottom;  // ef for layers > layer_lo, and for layer_lo
+    uint32_t n;                  // results per query
+    uint32_t *out_ids;           // nq x n
+    float *out_dists;            // nq x n or null
+    uint32_t *out_counts;        // nq or null
+    hnsw_query_stats *out_stats; // nq
+};
+
+class DeviceIndex {
+  public:
+    ~DeviceIndex() { release(); }
+    int upload(const HostIndex &idx, int device);
+    void release();
+    bool current(const HostIndex &idx) const { return valid && version_seen == idx.version; }
+
+    bool valid = false;
+    int device = -1;
+    uint64_t version_seen = 0;
+    uint64_t bytes = 0;
+    DevView view{};
+
+  private:
+    void *bufs_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+// row packing helpers shared by upload and tests
+uint32_t quant_half_bytes(uint32_t dim);
+uint32_t f32_row_stride(uint32_t dim);
+uint32_t adj_stride(uint64_t cap, uint32_t min_slots);
+
+// Launch the search kernel for `nblocks` queries on `stream`.  slots_log2 = log2 of the visited
+// hash table size (LDS), 0 = choose from ef.  Returns HNSW_OK or HNSW_ERR_ARG / HNSW_ERR_HIP.
+int launch_search(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint32_t slots_log2,
+                  hipStream_t stream);
+uint32_t default_slots_log2(uint32_t ef);
+uint32_t max_slots_log2(uint32_t ef);
+
+// out[i] = dist(point ids[i], query) for one query; d_q is the raw query (dim floats, device)
+int launch_distance_batch(const DevView &v, const float *d_q, const uint32_t *d_ids, uint64_t k,
+                          float *d_out, int32_t *d_status, hipStream_t stream);
+
+// exhaustive scan: every query against every point; partial top-k per (query, segment):
+// part_ids / part_dists are nq x nseg x k.  The host merges the segments.
+int launch_brute_force(const DevView &v, const float *d_Q, uint64_t nq, uint32_t k, uint32_t nseg,
+                       uint32_t *part_ids, float *part_dists, int32_t *d_status,
+                       hipStream_t stream);
+
+}  // namespace hx

@@ -1,0 +1,142 @@
+// host_index.h -- host side of libhnsw_mi355x: the index a caller mutates through the C ABI
+// (points + layered graph + params) and the build path (insert_bulk / insert_vec).
+//
+// The search hot path does NOT live here: it runs on the GPU from an HBM-resident snapshot of
+// this structure (device_index.h, search_kernels.hip).  Citations are relative to the reference
+// repository root.
+#pragma once
+
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/hnsw_mi355x.h"
+
+namespace hx {
+
+typedef uint32_t NodeID;  // graph/src/lib.rs:1
+
+// graph/src/dist.rs:4-38 -- total order: dist, then id
+struct Dist {
+    NodeID id;
+    float dist;
+};
+inline bool dist_lt(const Dist &a, const Dist &b) {
+    return a.dist < b.dist || (a.dist == b.dist && a.id < b.id);
+}
+inline bool dist_eq(const Dist &a, const Dist &b) { return a.dist == b.dist && a.id == b.id; }
+
+// hnsw/src/params.rs:5-13
+struct Params {
+    NodeID ep = 0;
+    uint64_t m = 0, mmax = 0, mmax0 = 0;
+    float ml = 0.0f;
+    uint64_t ef_cons = 0, dim = 0;
+};
+
+// ---- arithmetic (vectors crate), host side: used by the build path and the accessors ---------
+int quantize(const float *v, uint32_t d, float *min_out, float *delta_out, uint8_t *codes);
+float dist_quant(uint32_t d, const uint8_t *cx, float delta_x, float min_x, const uint8_t *cy,
+                 float delta_y, float min_y);
+float dist_full(uint32_t d, const float *x, const float *y);
+inline float default_ml(uint64_t m) { return 1.0f / std::log((float)m); }  // params.rs:15-17
+
+// a borrowed Point (points/src/point.rs:6-10)
+struct PointView {
+    NodeID id = 0;
+    const uint8_t *codes = nullptr;
+    float delta = 0.0f, min = 0.0f;
+    const float *vals = nullptr;
+};
+
+class Inserter;
+
+class HostIndex {
+  public:
+    HostIndex(uint32_t m, uint32_t ef_cons, uint32_t dim, int vec_kind);
+    HostIndex(const HostIndex &o);
+
+    // ---- points (points/src/points.rs SimplePoints, stored SoA) ----
+    int kind;
+    uint32_t dim;
+    std::vector<uint8_t> codes;     // QUANT8: N x dim
+    std::vector<float> mins, deltas;  // QUANT8: N
+    std::vector<float> vals;        // F32: N x dim
+    std::vector<uint8_t> levels;    // N
+    uint64_t len() const { return levels.size(); }
+    bool get_point(NodeID id, PointView *p) const;
+    float dist2other(const PointView &a, const PointView &b) const;
+
+    // ---- layered graph (graph/src/layers.rs, graph/src/graph.rs) ----
+    // A node of level L belongs to layers 0..L (layers.rs:63-70).  Layer 0 rows are indexed by
+    // id; a node's upper-layer rows are contiguous: row(id, l >= 1) = upper_base[id] + l - 1.
+    Params params;
+    std::vector<std::vector<NodeID>> layer_nodes;  // per layer, ascending id
+    std::vector<std::vector<NodeID>> adj0;
+    std::vector<uint32_t> upper_base;
+    std::vector<std::vector<NodeID>> adj_up;
+    uint64_t version = 0;  // bumped by every mutation; the device snapshot records what it saw
+
+    uint32_t nb_layers() const { return (uint32_t)layer_nodes.size(); }
+    uint64_t layer_m(uint32_t layer) const { return layer == 0 ? params.m * 2 : params.m; }
+    bool in_layer(uint32_t layer, NodeID id) const {
+        return id < len() && layer < nb_layers() && levels[id] >= layer;
+    }
+    std::vector<NodeID> &row(uint32_t layer, NodeID id) {
+        return layer == 0 ? adj0[id] : adj_up[upper_base[id] + layer - 1];
+    }
+    const std::vector<NodeID> &row(uint32_t layer, NodeID id) const {
+        return layer == 0 ? adj0[id] : adj_up[upper_base[id] + layer - 1];
+    }
+    // neighbours copied under the row's lock (graph.rs:103-113 locks the Mutex, copies the set)
+    bool neighbors_vec(uint32_t layer, NodeID id, std::vector<NodeID> *out) const;
+    bool degree(uint32_t layer, NodeID id, size_t *out) const;
+    int add_edge(uint32_t layer, NodeID a, NodeID b);
+    int remove_edge(uint32_t layer, NodeID a, NodeID b);
+    int isolate_node(uint32_t layer, NodeID node);
+    int replace_neighbors(uint32_t layer, NodeID node, const std::vector<NodeID> &nb);
+
+    // ---- build (hnsw/src/template.rs) ----
+    int store_points(const float *rows, uint64_t n, const uint8_t *levels_in,
+                     std::vector<NodeID> *ids_out);
+    int insert(NodeID point_id, Inserter &ins);
+    int insert_bulk(const float *rows, uint64_t n, uint32_t nb_threads, bool verbose,
+                    const uint8_t *levels_in);
+    int insert_vec(const float *v, int level, NodeID *out_id);
+    int import_points(const float *rows, uint64_t n, const uint8_t *levels_in);
+    int import_layer(uint32_t layer, uint64_t n_nodes, const NodeID *node_ids,
+                     const uint64_t *offsets, const NodeID *nbrs);
+    bool check_param_compliance() const;
+
+    // level draws when the caller gives none
+    void draw_levels(uint64_t n, uint8_t *out) const;
+
+  private:
+    void add_node_rows(NodeID id, uint32_t level);
+    void lock_row(uint32_t layer, NodeID id) const;
+    void unlock_row(uint32_t layer, NodeID id) const;
+    void ensure_locks();
+    mutable std::unique_ptr<std::atomic<uint8_t>[]> lock0_, lock_up_;
+    mutable size_t lock0_n_ = 0, lock_up_n_ = 0;
+};
+
+// persistence (template.rs:43-131)
+int save_index(const HostIndex &idx, const std::string &dir);
+int load_index(const std::string &dir, std::unique_ptr<HostIndex> *out);
+
+// rand 0.8.5 StdRng (ChaCha12) level sampler, believed-equivalent restatement
+void stdrng_levels(uint64_t seed, float ml, uint64_t n, uint8_t *out);
+
+// synthetic data
+int synth_rows(int recipe, uint64_t seed, uint64_t first_row, uint64_t n, uint32_t d, float *out,
+               uint32_t nb_threads);
+
+// thread-local error text
+void set_error(const char *fmt, ...);
+const char *get_error();
+
+}  // namespace hx

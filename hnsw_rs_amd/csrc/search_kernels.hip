@@ -1,0 +1,797 @@
+// search_kernels.hip -- the HNSW search hot path as hand-written HIP for gfx950 (MI355X, CDNA4).
+//
+// What runs here replaces, for a whole batch of queries at once,
+//   HNSW::ann_by_vector          hnsw/src/template.rs:306-335
+//   Searcher::search_layer       hnsw/src/template/searcher.rs:23-103
+//   Results (ordered sets)       hnsw/src/template/results.rs:26-33,96-116,148-180
+//   QuantVec::new / distance_unrolled   vectors/src/quant.rs:41-66,14-37
+//   FullVec::distance            vectors/src/full.rs:23-29
+//   Dist ordering                graph/src/dist.rs:30-38
+// and returns bit-identical ids (and distances) for the same index and query.
+//
+// Execution model: ONE 64-lane wavefront per query (one single-wave workgroup), everything a
+// query needs while it runs lives on chip:
+//   - `selected` and `candidates` (two BTreeSets in the reference) collapse into ONE sorted list
+//     of <= ef keys with an "expanded" bit: every element enters both sets together
+//     (searcher.rs:79-80,86-87), leaves `candidates` only by being expanded, and an element
+//     evicted from `selected` is > selected.last() forever, so popping it could only hit the
+//     `break` (searcher.rs:41-44).  key = dist_bits << 32 | id orders exactly like Dist::cmp for
+//     the non-negative, non-NaN distances a sqrt produces; bit 63 (never set by such a float) is
+//     the expanded flag.  The list is held in registers (lane l, register r = list[64 r + l]) and
+//     re-sorted through an LDS permutation buffer when a batch of neighbours is merged.
+//   - `visited` (an IntSet, cleared per layer, searcher.rs:101) is an open-addressing hash table
+//     in LDS filled with ds_cmpst (atomicCAS).
+//   - the (dequantised) query is staged in LDS / registers once.
+// Per expansion the wave loads one adjacency row (one coalesced 128-B load at m = 16), filters
+// it through the visited table, gathers the vector rows of the fresh neighbours (QUANT8: a lane
+// PAIR per neighbour, each lane streaming 4 of distance_unrolled's 8 running sums from its own
+// contiguous half row; F32: one lane per neighbour because FullVec's sum is one sequential
+// chain), and merges the batch into the list by rank (ballot + popcount), which is the
+// reference's streaming top-ef (searcher.rs:74-94) evaluated for the whole batch at once: the
+// final `selected` does not depend on the order in which a batch is applied.
+//
+// Float fidelity: compiled with -ffp-contract=off; no FMA may fuse `code * delta + min` or
+// `acc += t * t`; sqrt and the quantiser's division are the correctly rounded forms hipcc emits
+// by default.  Accumulation order is the reference's (quant.rs:23-36, full.rs:24-28).
+
+#include "device_index.h"
+
+namespace hx {
+
+typedef unsigned long long u64;
+
+static constexpr u64 KEY_INVALID = ~0ull;
+static constexpr u64 KEY_MASK = 0x7FFFFFFFFFFFFFFFull;  // drops the expanded flag
+static constexpr u64 KEY_EXPANDED = 1ull << 63;
+
+#define HX_MAX_R 8  // ef <= 64 * HX_MAX_R
+
+__device__ __forceinline__ u64 readlane64(u64 v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+// value held by the other lane of this lane's pair (lane ^ 1): DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ float pair_swap(float x) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ int pair_swap_i(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);
+}
+// Rust `f32 as u8`: saturating, NaN -> 0
+__device__ __forceinline__ uint32_t f32_as_u8(float x) {
+    if (!(x > 0.0f)) return 0;
+    if (x >= 255.0f) return 255;
+    return (uint32_t)x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// distance of this lane's share of one QUANT8 row (quant.rs:14-37).
+// P 16-byte pieces per half row; element e of the half sits at byte 8 + e.  Elements below nch4
+// are chunk elements (running sum e & 3 of this lane), elements [nch4, nch4 + rem) are the tail
+// and all go to running sum 0 of lane h == 0, in order, after its chunk elements.
+// yq: this half's dequantised query values in the same element order (LDS or registers).
+// ---------------------------------------------------------------------------------------------
+template <int P, int DS, typename QSrc>
+__device__ __forceinline__ void quant_half_sums(const uint4 (&w)[P], const QSrc &yq, int h,
+                                                uint32_t nch4, uint32_t rem, float (&acc)[4]) {
+    const float mn = __builtin_bit_cast(float, w[0].x);
+    const float delta = __builtin_bit_cast(float, w[0].y);
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const uint32_t dw[4] = {w[p].x, w[p].y, w[p].z, w[p].w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (p == 0 && j < 2) continue;  // header
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int e = 16 * p + 4 * j + k - 8;
+                if (DS > 0) {  // compile-time dimension: dead elements vanish
+                    constexpr int N4 = 4 * (DS / 8), RM = DS % 8;
+                    if (e >= N4 + RM) continue;
+                    const float x = ((float)((dw[j] >> (8 * k)) & 0xFFu) * delta) + mn;
+                    const float t = x - yq[e];
+                    const float t2 = t * t;
+                    if (e < N4)
+                        acc[k] += t2;
+                    else
+                        acc[0] += (h == 0) ? t2 : 0.0f;  // +0.0 leaves a non-negative sum as is
+                } else {
+                    const float x = ((float)((dw[j] >> (8 * k)) & 0xFFu) * delta) + mn;
+                    const float t = x - yq[e];
+                    const float t2 = t * t;
+                    const bool chunk = (uint32_t)e < nch4;
+                    const bool tail = !chunk && (uint32_t)e < nch4 + rem && h == 0;
+                    if (k == 0) {
+                        acc[0] += (chunk || tail) ? t2 : 0.0f;
+                    } else {
+                        acc[k] += chunk ? t2 : 0.0f;
+                        acc[0] += tail ? t2 : 0.0f;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage one query in LDS.  QUANT8: the query is quantised with its own min / delta exactly like
+// a stored vector (Point::new -> QuantVec::new, template.rs:313, quant.rs:41-66) and kept
+// dequantised, y = code * delta + min, split into the two half-row element orders:
+// yq[h * nq_half + i].  F32: the raw values.  Returns false when the query holds a NaN
+// (partial_cmp().unwrap() panics in the reference).
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ bool stage_query(const DevView &v, const float *qv, float *yq, int lane) {
+    const uint32_t d = v.dim;
+    bool bad = false;
+    if (KIND == HNSW_VEC_QUANT8) {
+        const uint32_t nq_half = v.half_bytes - 8;
+        float lo = __builtin_inff(), hi = -__builtin_inff();
+        for (uint32_t e = lane; e < d; e += 64) {
+            const float x = qv[e];
+            bad |= (x != x);
+            lo = fminf(lo, x);
+            hi = fmaxf(hi, x);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o));
+            hi = fmaxf(hi, __shfl_xor(hi, o));
+        }
+        const float delta = (hi - lo) / 255.0f;  // (ub - lb) / (2^8 - 1)
+        for (uint32_t e = lane; e < 2 * nq_half; e += 64) yq[e] = 0.0f;
+        __syncthreads();
+        const uint32_t full = d & ~7u;
+        for (uint32_t e = lane; e < d; e += 64) {
+            float b = (qv[e] - lo) / delta;
+            b += 0.5f;
+            const float y = ((float)f32_as_u8(floorf(b)) * delta) + lo;
+            uint32_t hh, i;
+            if (e < full) {
+                hh = (e & 7) >> 2;
+                i = 4 * (e >> 3) + (e & 3);
+            } else {
+                hh = 0;
+                i = v.nch4 + (e - full);
+            }
+            yq[hh * nq_half + i] = y;
+        }
+    } else {
+        for (uint32_t e = lane; e < d; e += 64) {
+            const float x = qv[e];
+            bad |= (x != x);
+            yq[e] = x;
+        }
+    }
+    __syncthreads();
+    return __ballot(bad) == 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Distance of one stored point to the staged query for ANY dimension (runtime loops): used by
+// the test-seam and brute-force kernels, and by the search kernel when no specialised variant
+// fits.  QUANT8: valid on the even lane of the pair; F32: per lane.
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ float dist_any_dim(const DevView &v, uint32_t id, bool active, int h,
+                                              const float *yq) {
+    if (KIND == HNSW_VEC_QUANT8) {
+        const float *yh = yq + h * (v.half_bytes - 8);
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (active) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(
+                v.rows + (size_t)id * v.row_stride + (size_t)h * v.half_bytes);
+            const uint32_t np = v.half_bytes >> 4;
+            const uint4 w0 = src[0];
+            const float mn = __builtin_bit_cast(float, w0.x);
+            const float delta = __builtin_bit_cast(float, w0.y);
+            // groups of 4 pieces so that 64 B per lane are in flight
+            for (uint32_t p0 = 0; p0 < np; p0 += 4) {
+                uint4 w[4];
+#pragma unroll
+                for (int p = 0; p < 4; p++)
+                    w[p] = (p0 + p < np) ? src[p0 + p] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const uint32_t dw[4] = {w[p].x, w[p].y, w[p].z, w[p].w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int e = 16 * (int)(p0 + p) + 4 * j + k - 8;
+                            const float x = ((float)((dw[j] >> (8 * k)) & 0xFFu) * delta) + mn;
+                            const bool chunk = e >= 0 && (uint32_t)e < v.nch4;
+                            const bool tail =
+                                e >= 0 && !chunk && (uint32_t)e < v.nch4 + v.rem && h == 0;
+                            const float y = (chunk || tail) ? yh[e] : 0.0f;
+                            const float t = x - y;
+                            const float t2 = t * t;
+                            if (k == 0) {
+                                acc[0] += (chunk || tail) ? t2 : 0.0f;
+                            } else {
+                                acc[k] += chunk ? t2 : 0.0f;
+                                acc[0] += tail ? t2 : 0.0f;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // acc.iter().sum(): ((((((a0+a1)+a2)+a3)+a4)+a5)+a6)+a7 with a4..a7 on the odd lane
+        const float b0 = pair_swap(acc[0]), b1 = pair_swap(acc[1]), b2 = pair_swap(acc[2]),
+                    b3 = pair_swap(acc[3]);
+        float s = 0.0f;
+        s += acc[0];
+        s += acc[1];
+        s += acc[2];
+        s += acc[3];
+        s += b0;
+        s += b1;
+        s += b2;
+        s += b3;
+        return __builtin_sqrtf(s);
+    } else {
+        // FullVec: one sequential sum per candidate, one candidate per lane (full.rs:24-28)
+        float s = 0.0f;
+        if (active) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(v.rows + (size_t)id * v.row_stride);
+            const uint32_t np = v.row_stride >> 4, d = v.dim;
+            for (uint32_t p0 = 0; p0 < np; p0 += 8) {
+                uint4 w[8];
+#pragma unroll
+                for (int p = 0; p < 8; p++)
+                    w[p] = (p0 + p < np) ? src[p0 + p] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int p = 0; p < 8; p++) {
+                    const uint32_t dw[4] = {w[p].x, w[p].y, w[p].z, w[p].w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t e = 4 * (p0 + p) + j;
+                        const bool in = e < d;
+                        const float y = in ? yq[e] : 0.0f;
+                        const float t = __builtin_bit_cast(float, dw[j]) - y;
+                        const float t2 = t * t;
+                        s += in ? t2 : 0.0f;  // +0.0 leaves a non-negative sum unchanged
+                    }
+                }
+            }
+        }
+        return __builtin_sqrtf(s);
+    }
+}
+
+// LDS-resident query values of one half
+struct QLds {
+    const float *p;
+    __device__ __forceinline__ float operator[](int e) const { return p[e]; }
+};
+// register-resident query values (compile-time dimension)
+template <int N>
+struct QRegs {
+    float v[N];
+    __device__ __forceinline__ float operator[](int e) const { return v[e]; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Per-wave search state and the pieces of search_layer
+// ---------------------------------------------------------------------------------------------
+template <int R>
+struct WaveList {
+    u64 L[R];         // list[64 r + lane]; KEY_INVALID beyond n_cur
+    uint32_t n_cur;   // wave-uniform
+    u64 last_key;     // key (flag dropped) of position ef - 1 when the list is full
+
+    // Merge the wave's candidate keys (KEY_INVALID = none) into the sorted list, keeping the ef
+    // smallest: streaming top-ef of searcher.rs:74-94 for a whole batch (order-independent).
+    __device__ __forceinline__ void merge(u64 key, uint32_t ef, u64 *perm, int lane) {
+        const bool full = n_cur >= ef;
+        const bool surv = key != KEY_INVALID && (!full || key < last_key);
+        u64 smask = __ballot(surv);
+        if (smask == 0) return;
+        const uint32_t m = (uint32_t)__popcll(smask);
+        uint32_t shift[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) shift[r] = 0;
+        uint32_t my_rank = 0;
+        u64 it = smask;
+        while (it) {  // wave-uniform loop over the survivors
+            const int j = __ffsll((long long)it) - 1;
+            it &= it - 1;
+            const u64 e = readlane64(key, j);
+            uint32_t below = 0;  // list entries smaller than e
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const bool lt = (L[r] & KEY_MASK) < e;  // invalid entries are the maximum
+                below += (uint32_t)__popcll(__ballot(lt));
+                shift[r] += lt ? 0u : 1u;
+            }
+            if (surv && e < key) my_rank++;
+            if (lane == j) my_rank += below;
+        }
+        // scatter to the new positions through LDS (all reads of L happened above)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t idx = 64u * r + lane;
+            const uint32_t np = idx + shift[r];
+            if (idx < n_cur && np < ef) perm[np] = L[r];
+        }
+        if (surv && my_rank < ef) perm[my_rank] = key;
+        n_cur = min(n_cur + m, ef);
+        __syncthreads();  // single-wave workgroup: orders the LDS writes before the reads
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t idx = 64u * r + lane;
+            L[r] = idx < n_cur ? perm[idx] : KEY_INVALID;
+        }
+        __syncthreads();
+        refresh_last(ef);
+    }
+
+    __device__ __forceinline__ void refresh_last(uint32_t ef) {
+        if (n_cur >= ef) {
+            const uint32_t pos = ef - 1;
+            u64 k = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if ((pos >> 6) == (uint32_t)r) k = readlane64(L[r], pos & 63);
+            last_key = k & KEY_MASK;
+        } else {
+            last_key = KEY_INVALID;
+        }
+    }
+
+    // position of the smallest entry not expanded yet, -1 if none (the loop of searcher.rs:35)
+    __device__ __forceinline__ int first_unexpanded(int lane) const {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t idx = 64u * r + lane;
+            const u64 mk = __ballot(idx < n_cur && (L[r] & KEY_EXPANDED) == 0);
+            if (mk) return 64 * r + (__ffsll((long long)mk) - 1);
+        }
+        return -1;
+    }
+};
+
+// LDS visited table: open addressing, linear probing, key = node id, empty = 0xFFFFFFFF.
+// Returns true when id was not present (IntSet::insert, results.rs:101-103).
+__device__ __forceinline__ bool visited_insert(uint32_t *tab, uint32_t hmask, uint32_t slots_log2,
+                                               uint32_t id) {
+    uint32_t s = (id * 0x9E3779B1u) >> (32 - slots_log2);
+    while (true) {
+        const uint32_t old = atomicCAS(&tab[s], HX_EMPTY_SLOT, id);
+        if (old == HX_EMPTY_SLOT) return true;
+        if (old == id) return false;
+        s = (s + 1) & hmask;
+    }
+}
+
+template <int KIND, int P, int DS, int R>
+__global__ void __launch_bounds__(64)
+hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t q = a.qsel ? a.qsel[blockIdx.x] : blockIdx.x;
+    uint32_t *htab = reinterpret_cast<uint32_t *>(smem);
+    const uint32_t hslots = 1u << slots_log2, hmask = hslots - 1;
+    u64 *perm = reinterpret_cast<u64 *>(smem + 4ull * hslots);
+    float *yq = reinterpret_cast<float *>(perm + 64 * R);
+    const uint32_t vis_limit = hslots - (hslots >> 2);  // 75 % load at most
+
+    constexpr int LPC = (KIND == HNSW_VEC_QUANT8) ? 2 : 1;  // lanes per candidate
+    constexpr int CHUNK = 64 / LPC;                         // adjacency slots per pass
+    const int h = (LPC == 2) ? (lane & 1) : 0;
+    const int cslot = lane / LPC;
+
+    const uint32_t d = v.dim;
+    const float *qv = a.Q + (size_t)q * d;
+    uint32_t n_dist = 0, n_exp = 0, sum_deg = 0;
+    int32_t status = HNSW_OK;
+
+    // ---- stage the query (Point::new -> QuantVec::new for QUANT8, template.rs:313) ----
+    const uint32_t nq_half = (KIND == HNSW_VEC_QUANT8) ? (v.half_bytes - 8) : 0;
+    if (!stage_query<KIND>(v, qv, yq, lane)) status = HNSW_ERR_NAN_INPUT;
+
+    // query values of this lane in registers when the dimension is a compile-time constant
+    constexpr int NQR = (KIND == HNSW_VEC_QUANT8 && DS > 0) ? (4 * (DS / 8) + DS % 8) : 1;
+    QRegs<NQR> qreg;
+    if (KIND == HNSW_VEC_QUANT8 && DS > 0) {
+#pragma unroll
+        for (int e = 0; e < NQR; e++) qreg.v[e] = yq[h * nq_half + e];
+    }
+    const QLds qlds{yq + h * nq_half};
+
+    WaveList<R> wl;
+#pragma unroll
+    for (int r = 0; r < R; r++) wl.L[r] = KEY_INVALID;
+    wl.n_cur = 0;
+    wl.last_key = KEY_INVALID;
+
+    // ---- distance of one candidate per lane group; returns the key on the group's first lane
+    auto eval_key = [&](uint32_t id, bool active) -> u64 {
+        float dist = 0.0f;
+        if (KIND == HNSW_VEC_QUANT8 && P > 0) {
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (active) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(
+                    v.rows + (size_t)id * v.row_stride + (size_t)h * v.half_bytes);
+                uint4 w[P > 0 ? P : 1];
+#pragma unroll
+                for (int p = 0; p < P; p++) w[p] = src[p];
+                if (DS > 0)
+                    quant_half_sums<(P > 0 ? P : 1), DS>(w, qreg, h, v.nch4, v.rem, acc);
+                else
+                    quant_half_sums<(P > 0 ? P : 1), 0>(w, qlds, h, v.nch4, v.rem, acc);
+            }
+            // acc.iter().sum(): ((((((a0+a1)+a2)+a3)+a4)+a5)+a6)+a7 with a4..a7 on the odd lane
+            const float b0 = pair_swap(acc[0]), b1 = pair_swap(acc[1]), b2 = pair_swap(acc[2]),
+                        b3 = pair_swap(acc[3]);
+            float s = 0.0f;
+            s += acc[0];
+            s += acc[1];
+            s += acc[2];
+            s += acc[3];
+            s += b0;
+            s += b1;
+            s += b2;
+            s += b3;
+            dist = __builtin_sqrtf(s);
+        } else {
+            dist = dist_any_dim<KIND>(v, id, active, h, yq);
+        }
+        const bool first = (LPC == 1) || (h == 0);
+        if (!(active && first)) return KEY_INVALID;
+        if (dist != dist) {
+            status = HNSW_ERR_NAN_INPUT;  // Dist::cmp would panic (dist.rs:32)
+            return KEY_INVALID;
+        }
+        return ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | id;
+    };
+
+    // ---- one pass over up to CHUNK neighbour ids (one per lane group) ----
+    auto process = [&](uint32_t id, bool valid, bool visit, uint32_t ef_l) {
+        bool fresh = valid;
+        if (visit) {
+            bool f = false;
+            if (valid && h == 0) f = visited_insert(htab, hmask, slots_log2, id);
+            if (LPC == 2) f = (pair_swap_i(f ? 1 : 0) | (f ? 1 : 0)) != 0;
+            fresh = f;
+        }
+        const u64 fm = __ballot(fresh && h == 0);
+        if (fm == 0) return;
+        n_dist += (uint32_t)__popcll(fm);
+        u64 key = eval_key(id, fresh);
+        if (__ballot(status != HNSW_OK)) status = HNSW_ERR_NAN_INPUT;
+        wl.merge(key, ef_l, perm, lane);
+    };
+
+    uint32_t n_vis = 0;
+    if (status == HNSW_OK) {
+        // ---- entry set: {ep} (template.rs:316-319) or the caller's (search_layer seam) ----
+        const uint32_t n_entry = a.entries ? a.n_entry : 1;
+        const uint32_t ef_first = max(1u, (a.layer_hi > a.layer_lo) ? a.ef_upper : a.ef_bottom);
+        for (uint32_t base = 0; base < n_entry; base += CHUNK) {
+            const uint32_t i = base + cslot;
+            const bool valid = i < n_entry;
+            uint32_t id = 0;
+            if (valid) id = a.entries ? a.entries[i] : v.ep;
+            if (__ballot(valid && id >= v.n_points)) {
+                status = HNSW_ERR_ARG;
+                break;
+            }
+            // the reference keeps every entry it is given; an entry set larger than ef is
+            // rejected by the host side
+            process(id, valid, false, max(ef_first, n_entry));
+        }
+    }
+
+    for (int layer = a.layer_hi; status == HNSW_OK && layer >= a.layer_lo; layer--) {
+        const uint32_t ef_l = max(1u, layer > a.layer_lo ? a.ef_upper : a.ef_bottom);
+        // visited.clear() (searcher.rs:101) / fresh Results: empty table
+        for (uint32_t s = lane; s < hslots; s += 64) htab[s] = HX_EMPTY_SLOT;
+        __syncthreads();
+        n_vis = 0;
+        // candidates ∪= selected, visited ∪= ids(selected)  (searcher.rs:32-33)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t idx = 64u * r + lane;
+            if (idx < wl.n_cur) {
+                wl.L[r] &= KEY_MASK;
+                visited_insert(htab, hmask, slots_log2, (uint32_t)wl.L[r]);
+            }
+        }
+        n_vis = wl.n_cur;
+        wl.refresh_last(ef_l);
+        const uint32_t S = layer == 0 ? v.S0 : v.S1;
+
+        while (true) {
+            const int cpos = wl.first_unexpanded(lane);
+            if (cpos < 0) break;  // candidates exhausted / only worse ones left
+            // pop it: mark expanded, fetch its id
+            uint32_t cid = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if ((cpos >> 6) == r) {
+                    cid = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wl.L[r], cpos & 63);
+                    if (lane == (cpos & 63)) wl.L[r] |= KEY_EXPANDED;
+                }
+            }
+            n_exp++;
+            const uint32_t *row;
+            if (layer == 0) {
+                row = v.adj0 + (size_t)cid * S;
+            } else {
+                const uint32_t ub = v.upper_base[cid];
+                if (ub == HX_EMPTY_SLOT) {  // Graph::neighbors_vec -> NodeNotInGraph
+                    status = HNSW_ERR_NODE_NOT_IN_GRAPH;
+                    break;
+                }
+                row = v.adj_up + ((size_t)ub + layer - 1) * S;
+            }
+            uint32_t ovf = HX_EMPTY_SLOT;
+            for (uint32_t c0 = 0; c0 < S; c0 += CHUNK) {
+                const uint32_t slot = c0 + cslot;
+                uint32_t nb = HX_EMPTY_SLOT;
+                if (slot < S) nb = row[slot];
+                const bool is_ptr = nb != HX_EMPTY_SLOT && (nb & HX_OVF_FLAG);
+                const bool valid = nb != HX_EMPTY_SLOT && !is_ptr;
+                const u64 pm = __ballot(is_ptr);
+                if (pm) ovf = (uint32_t)__builtin_amdgcn_readlane((int)nb, __ffsll((long long)pm) - 1) & ~HX_OVF_FLAG;
+                const uint32_t cnt = (uint32_t)__popcll(__ballot(valid && h == 0));
+                if (cnt == 0) continue;
+                sum_deg += cnt;
+                if (n_vis + cnt > vis_limit) {
+                    status = HNSW_ERR_OVERFLOW;
+                    break;
+                }
+                n_vis += cnt;
+                process(nb, valid, true, ef_l);
+                if (status != HNSW_OK) break;
+            }
+            if (status == HNSW_OK && ovf != HX_EMPTY_SLOT) {  // degree > S: the rest of the row
+                const uint32_t lo = v.ovf_off[ovf], hi = v.ovf_off[ovf + 1];
+                for (uint32_t base = lo; base < hi; base += CHUNK) {
+                    const uint32_t i = base + cslot;
+                    const bool valid = i < hi;
+                    const uint32_t nb = valid ? v.ovf_nbrs[i] : HX_EMPTY_SLOT;
+                    const uint32_t cnt = (uint32_t)__popcll(__ballot(valid && h == 0));
+                    sum_deg += cnt;
+                    if (n_vis + cnt > vis_limit) {
+                        status = HNSW_ERR_OVERFLOW;
+                        break;
+                    }
+                    n_vis += cnt;
+                    process(nb, valid, true, ef_l);
+                    if (status != HNSW_OK) break;
+                }
+            }
+            if (status != HNSW_OK) break;
+        }
+    }
+
+    // ---- get_top_selected(n) (results.rs:59-61): the first n of the ascending list ----
+    const uint32_t count = status == HNSW_OK ? min(a.n, wl.n_cur) : 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t idx = 64u * r + lane;
+        if (idx < a.n) {
+            const bool have = idx < count;
+            a.out_ids[(size_t)q * a.n + idx] = have ? (uint32_t)wl.L[r] : HX_EMPTY_SLOT;
+            if (a.out_dists)
+                a.out_dists[(size_t)q * a.n + idx] =
+                    have ? __builtin_bit_cast(float, (uint32_t)((wl.L[r] & KEY_MASK) >> 32))
+                         : __builtin_inff();
+        }
+    }
+    for (uint32_t idx = 64u * R + lane; idx < a.n; idx += 64) {  // n > list capacity: padding
+        a.out_ids[(size_t)q * a.n + idx] = HX_EMPTY_SLOT;
+        if (a.out_dists) a.out_dists[(size_t)q * a.n + idx] = __builtin_inff();
+    }
+    if (lane == 0) {
+        if (a.out_counts) a.out_counts[q] = count;
+        hnsw_query_stats st;
+        st.n_dist = n_dist;
+        st.n_exp = n_exp;
+        st.sum_deg = sum_deg;
+        st.status = status;
+        a.out_stats[q] = st;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+
+uint32_t default_slots_log2(uint32_t ef) {
+    if (ef <= 96) return 12;   // 4096 slots, 16 KiB
+    if (ef <= 224) return 13;
+    if (ef <= 448) return 14;
+    return 15;                 // 128 KiB
+}
+uint32_t max_slots_log2(uint32_t) { return 15; }
+
+template <int KIND, int P, int DS, int R>
+static int launch_one(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint32_t slots_log2,
+                      hipStream_t stream) {
+    const size_t yq_bytes =
+        (KIND == HNSW_VEC_QUANT8) ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4;
+    size_t lds = (4ull << slots_log2) + 64ull * R * 8 + ((yq_bytes + 15) & ~15ull);
+    auto kern = hx_search_kernel<KIND, P, DS, R>;
+    if (lds > 160 * 1024) {
+        set_error("search needs %zu bytes of LDS (> 160 KiB)", lds);
+        return HNSW_ERR_ARG;
+    }
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+            return HNSW_ERR_HIP;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64), lds, stream, v, a, slots_log2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("search kernel launch: %s", hipGetErrorString(e));
+        return HNSW_ERR_HIP;
+    }
+    return HNSW_OK;
+}
+
+template <int KIND, int P, int DS>
+static int launch_r(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint32_t slots_log2,
+                    hipStream_t stream, uint32_t ef_max) {
+    if (ef_max <= 64) return launch_one<KIND, P, DS, 1>(v, a, nblocks, slots_log2, stream);
+    if (ef_max <= 128) return launch_one<KIND, P, DS, 2>(v, a, nblocks, slots_log2, stream);
+    if (ef_max <= 256) return launch_one<KIND, P, DS, 4>(v, a, nblocks, slots_log2, stream);
+    if (ef_max <= 512) return launch_one<KIND, P, DS, 8>(v, a, nblocks, slots_log2, stream);
+    set_error("ef = %u is above the supported maximum of %d", ef_max, 64 * HX_MAX_R);
+    return HNSW_ERR_ARG;
+}
+
+int launch_search(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint32_t slots_log2,
+                  hipStream_t stream) {
+    if (nblocks == 0) return HNSW_OK;
+    uint32_t ef_max = std::max(1u, a.ef_bottom);
+    if (a.layer_hi > a.layer_lo) ef_max = std::max(ef_max, a.ef_upper);
+    if (a.entries) ef_max = std::max(ef_max, a.n_entry);
+    if (slots_log2 == 0) slots_log2 = default_slots_log2(ef_max);
+    if (v.kind == HNSW_VEC_QUANT8) {
+        const uint32_t P = v.half_bytes / 16;
+        if (v.dim == 100) return launch_r<HNSW_VEC_QUANT8, 4, 100>(v, a, nblocks, slots_log2, stream, ef_max);
+        switch (P) {
+            case 1: return launch_r<HNSW_VEC_QUANT8, 1, 0>(v, a, nblocks, slots_log2, stream, ef_max);
+            case 2: return launch_r<HNSW_VEC_QUANT8, 2, 0>(v, a, nblocks, slots_log2, stream, ef_max);
+            case 3: return launch_r<HNSW_VEC_QUANT8, 3, 0>(v, a, nblocks, slots_log2, stream, ef_max);
+            case 4: return launch_r<HNSW_VEC_QUANT8, 4, 0>(v, a, nblocks, slots_log2, stream, ef_max);
+            case 5: return launch_r<HNSW_VEC_QUANT8, 5, 0>(v, a, nblocks, slots_log2, stream, ef_max);
+            default: return launch_r<HNSW_VEC_QUANT8, 0, 0>(v, a, nblocks, slots_log2, stream, ef_max);
+        }
+    }
+    return launch_r<HNSW_VEC_F32, 0, 0>(v, a, nblocks, slots_log2, stream, ef_max);
+}
+
+// ---------------------------------------------------------------------------------------------
+// distance_batch: VecBase::dist2many (vectors/src/lib.rs:17-22) for one query -- the search
+// kernel restricted to "evaluate these ids": every id is an entry, results come back in list
+// order, so this launcher runs the kernel with ef = n = k and then un-sorts on the host side.
+// (Kept simple on purpose: it is a test seam, not a hot path.)
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ void __launch_bounds__(64)
+hx_distance_kernel(const DevView v, const float *q, const uint32_t *ids, uint64_t k, float *out,
+                   int32_t *status_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *yq = reinterpret_cast<float *>(smem);
+    const int lane = threadIdx.x;
+    constexpr int LPC = (KIND == HNSW_VEC_QUANT8) ? 2 : 1;
+    constexpr int CHUNK = 64 / LPC;
+    const int h = (LPC == 2) ? (lane & 1) : 0;
+    int32_t status = stage_query<KIND>(v, q, yq, lane) ? HNSW_OK : HNSW_ERR_NAN_INPUT;
+    for (uint64_t base = (uint64_t)blockIdx.x * CHUNK; base < k;
+         base += (uint64_t)gridDim.x * CHUNK) {
+        const uint64_t i = base + lane / LPC;
+        const bool active = i < k;
+        const uint32_t id = active ? ids[i] : 0;
+        const bool ok = active && id < v.n_points;
+        const float dist = dist_any_dim<KIND>(v, id, ok, h, yq);
+        if (active && h == 0) {
+            if (!ok) status = HNSW_ERR_ARG;
+            out[i] = ok ? dist : __builtin_nanf("");
+        }
+    }
+    if (status != HNSW_OK) atomicMin(status_out, status);
+}
+
+// ---------------------------------------------------------------------------------------------
+// brute force: exact top-k of every query over ALL points under the index's own metric (the
+// reference's ground truth: helpers/glove.rs:94-109, template.rs:531-541).  Block (seg, q) scans
+// one contiguous segment of the ids and keeps its k best in the same sorted list the search
+// uses; the host merges the nseg partial lists of a query.
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ void __launch_bounds__(64)
+hx_brute_kernel(const DevView v, const float *Q, uint32_t k, uint32_t nseg, uint32_t *part_ids,
+                float *part_dists, int32_t *status_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *perm = reinterpret_cast<u64 *>(smem);
+    float *yq = reinterpret_cast<float *>(perm + 64);
+    const int lane = threadIdx.x;
+    const uint32_t seg = blockIdx.x, q = blockIdx.y;
+    constexpr int LPC = (KIND == HNSW_VEC_QUANT8) ? 2 : 1;
+    constexpr int CHUNK = 64 / LPC;
+    const int h = (LPC == 2) ? (lane & 1) : 0;
+    int32_t status = stage_query<KIND>(v, Q + (size_t)q * v.dim, yq, lane) ? HNSW_OK : HNSW_ERR_NAN_INPUT;
+    WaveList<1> wl;
+    wl.L[0] = KEY_INVALID;
+    wl.n_cur = 0;
+    wl.last_key = KEY_INVALID;
+    const uint64_t per = ((uint64_t)v.n_points + nseg - 1) / nseg;
+    const uint64_t lo = per * seg, hi = min((uint64_t)v.n_points, lo + per);
+    for (uint64_t base = lo; base < hi; base += CHUNK) {
+        const uint64_t i = base + lane / LPC;
+        const bool active = i < hi;
+        const float dist = dist_any_dim<KIND>(v, (uint32_t)i, active, h, yq);
+        u64 key = KEY_INVALID;
+        if (active && h == 0) {
+            if (dist != dist)
+                status = HNSW_ERR_NAN_INPUT;
+            else
+                key = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | (uint32_t)i;
+        }
+        wl.merge(key, k, perm, lane);
+    }
+    if ((uint32_t)lane < k) {
+        const size_t o = ((size_t)q * nseg + seg) * k + lane;
+        const bool have = (uint32_t)lane < wl.n_cur;
+        part_ids[o] = have ? (uint32_t)wl.L[0] : HX_EMPTY_SLOT;
+        part_dists[o] = have ? __builtin_bit_cast(float, (uint32_t)(wl.L[0] >> 32)) : __builtin_inff();
+    }
+    if (__ballot(status != HNSW_OK) && lane == 0) atomicMin(status_out, HNSW_ERR_NAN_INPUT);
+}
+
+int launch_brute_force(const DevView &v, const float *d_Q, uint64_t nq, uint32_t k, uint32_t nseg,
+                       uint32_t *part_ids, float *part_dists, int32_t *d_status,
+                       hipStream_t stream) {
+    if (nq == 0) return HNSW_OK;
+    if (k == 0 || k > 64 || nq > 65535) {
+        set_error("brute force supports 1 <= k <= 64 and at most 65535 queries per call");
+        return HNSW_ERR_ARG;
+    }
+    const size_t lds =
+        64 * 8 + (((v.kind == HNSW_VEC_QUANT8 ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4) + 15) & ~15ull);
+    if (v.kind == HNSW_VEC_QUANT8)
+        hipLaunchKernelGGL(hx_brute_kernel<HNSW_VEC_QUANT8>, dim3(nseg, (uint32_t)nq), dim3(64), lds,
+                           stream, v, d_Q, k, nseg, part_ids, part_dists, d_status);
+    else
+        hipLaunchKernelGGL(hx_brute_kernel<HNSW_VEC_F32>, dim3(nseg, (uint32_t)nq), dim3(64), lds,
+                           stream, v, d_Q, k, nseg, part_ids, part_dists, d_status);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("brute force kernel launch: %s", hipGetErrorString(e));
+        return HNSW_ERR_HIP;
+    }
+    return HNSW_OK;
+}
+
+int launch_distance_batch(const DevView &v, const float *d_q, const uint32_t *d_ids, uint64_t k,
+                          float *d_out, int32_t *d_status, hipStream_t stream) {
+    if (k == 0) return HNSW_OK;
+    const size_t lds =
+        ((v.kind == HNSW_VEC_QUANT8 ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4) + 15) & ~15ull;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(2048, (k + 31) / 32);
+    if (v.kind == HNSW_VEC_QUANT8)
+        hipLaunchKernelGGL(hx_distance_kernel<HNSW_VEC_QUANT8>, dim3(grid), dim3(64), lds, stream, v,
+                           d_q, d_ids, k, d_out, d_status);
+    else
+        hipLaunchKernelGGL(hx_distance_kernel<HNSW_VEC_F32>, dim3(grid), dim3(64), lds, stream, v,
+                           d_q, d_ids, k, d_out, d_status);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("distance kernel launch: %s", hipGetErrorString(e));
+        return HNSW_ERR_HIP;
+    }
+    return HNSW_OK;
+}
+
+}  // namespace hx

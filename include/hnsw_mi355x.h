@@ -1,0 +1,201 @@
+/*
+ * hnsw_mi355x.h -- C ABI of libhnsw_mi355x.so: an MI355X-native (gfx950 / CDNA4) HNSW engine that
+ * drops in behind the public API of the Rust `hnsw` crate of Gumo-A/hnsw_rs.
+ *
+ * The reference has no FFI seam of its own: callers link the `hnsw` crate and use
+ * hnsw::template::HNSW directly.  The seam preserved here is that public Rust API; a same-named
+ * Rust shim (shim-rust/, source only) binds these entry points -- see INTEGRATION.md.
+ * Every entry point cites the reference item it replaces (paths relative to the reference
+ * repository root).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every in/out buffer, nothing is retained
+ *     after return; an opaque handle owns the host index and its HBM-resident snapshot.
+ *   - every fallible call returns an int status (0 = HNSW_OK, < 0 = error); the text of the
+ *     last error on the calling thread is available from hnsw_last_error().  Nothing unwinds or
+ *     aborts across the ABI; where the reference panics (dim mismatch, NaN distance) the shim
+ *     maps the status back to a panic, where it returns Err(String) to Err(String).
+ *   - vectors are row-major float32; ids are the reference's NodeID = u32 (graph/src/lib.rs:1),
+ *     dense 0..N-1 in insertion order (points/src/points.rs:64-73); UINT32_MAX pads id outputs.
+ *   - search runs ONLY on the GPU (hand-written HIP, gfx950).  There is no CPU fallback: without
+ *     a usable device the search entry points fail with HNSW_ERR_NO_DEVICE / HNSW_ERR_HIP.
+ *   - concurrent searches on one handle are safe (the reference's ann_by_vector takes &self);
+ *     insert_* must not run concurrently with anything else on the same handle.
+ */
+#ifndef HNSW_MI355X_H
+#define HNSW_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------- */
+#define HNSW_OK 0
+#define HNSW_ERR_BAD_DIM (-1)           /* template.rs:253-262 panics */
+#define HNSW_ERR_NAN_INPUT (-2)         /* graph/src/dist.rs:32, vectors/src/quant.rs:44,48 panic */
+#define HNSW_ERR_NODE_NOT_IN_GRAPH (-3) /* searcher.rs:45-50 Err(String) */
+#define HNSW_ERR_IO (-4)                /* template.rs:75-93 Err(String) / save panics */
+#define HNSW_ERR_HIP (-5)
+#define HNSW_ERR_RCCL (-6)
+#define HNSW_ERR_OOM (-7)
+#define HNSW_ERR_ARG (-8)
+#define HNSW_ERR_EMPTY (-9)             /* index has no points (template.rs:318 unwrap panics) */
+#define HNSW_ERR_NO_DEVICE (-10)
+#define HNSW_ERR_OVERFLOW (-11)         /* internal scratch exhausted even after the retry path */
+#define HNSW_ERR_SELF_CONNECTION (-12)  /* graph/src/graph.rs:38-40 */
+
+/* ---- vector kinds ------------------------------------------------------------------------- */
+/* points/src/point.rs:4  `type VecType = QuantVec` is what the reference ships: 8-bit scalar
+ * quantisation with on-the-fly dequantised f32 L2 (vectors/src/quant.rs).  HNSW_VEC_F32 is the
+ * reference's alternate `VecType = FullVec` (vectors/src/full.rs). */
+#define HNSW_VEC_QUANT8 0
+#define HNSW_VEC_F32 1
+
+typedef struct hnsw_index hnsw_index;
+
+/* hnsw/src/params.rs:5-13 `pub struct Params` (a public field of HNSW, template.rs:37) */
+typedef struct hnsw_params {
+    uint32_t ep;
+    uint32_t vec_kind;
+    uint64_t m;
+    uint64_t mmax;
+    uint64_t mmax0;
+    float ml;
+    uint32_t _pad;
+    uint64_t ef_cons;
+    uint64_t dim;
+} hnsw_params;
+
+/* per-query traversal counters (the reference has none; they define the algorithmic bytes of
+ * the roofline report): n_dist = distance evaluations (incl. the entry point), n_exp = expanded
+ * candidates, sum_deg = sum of the degrees of the expanded adjacency rows. */
+typedef struct hnsw_query_stats {
+    uint32_t n_dist;
+    uint32_t n_exp;
+    uint32_t sum_deg;
+    int32_t status; /* per-query status (HNSW_OK or an error code) */
+} hnsw_query_stats;
+
+const char *hnsw_last_error(void);
+const char *hnsw_version(void);
+
+/* ---- construction -------------------------------------------------------------------------- */
+/* HNSW::new(m, ef_cons: Option<usize>, dim), template.rs:133-144; ef_cons == 0 means None
+ * (defaults ef_cons = 2m, mmax = m, mmax0 = 2m, ml = 1/ln(m): params.rs:20-42). */
+int hnsw_create(uint32_t m, uint32_t ef_cons, uint32_t dim, int vec_kind, hnsw_index **out);
+void hnsw_free(hnsw_index *h);
+/* #[derive(Clone)] on HNSW, template.rs:35 (benches clone the index, hnsw_benchmarks.rs:23) */
+int hnsw_clone(const hnsw_index *h, hnsw_index **out);
+
+int hnsw_get_params(const hnsw_index *h, hnsw_params *out);
+/* params.ep is a public field; the reference re-picks it in hash order at every store
+ * (template.rs:283-290) -- here the default is the smallest id on the top layer. */
+int hnsw_set_ep(hnsw_index *h, uint32_t ep);
+
+/* ---- build --------------------------------------------------------------------------------- */
+/* HNSW::insert_bulk(self, vectors: Vec<Vec<f32>>, nb_threads, verbose), template.rs:388-444.
+ * rows is n x dim row-major (the shim flattens Vec<Vec<f32>> and checks every row length,
+ * returning HNSW_ERR_BAD_DIM where template.rs:253-262 panics).  May be called repeatedly. */
+int hnsw_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads, int verbose);
+/* same, with the level of every new point given explicitly (levels[n]; NULL = draw them).  The
+ * reference draws levels from rand's StdRng re-seeded with 0 at every store
+ * (points/src/points.rs:39-48,148-160); rand is not part of the reference tree, so
+ * reproducible tests pass levels in. */
+int hnsw_insert_bulk_levels(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads,
+                            int verbose, const uint8_t *levels);
+/* HNSW::insert_vec(&mut self, &Vec<f32>) -> Result<NodeID, String>, template.rs:165-173 */
+int hnsw_insert_vec(hnsw_index *h, const float *v, uint32_t *out_id);
+int hnsw_insert_vec_level(hnsw_index *h, const float *v, int level /* < 0: draw */, uint32_t *out_id);
+
+/* Adopt a prebuilt graph (e.g. one built by another implementation of the reference) instead of
+ * building: points first, then layers 0,1,2,... as CSR over ascending node ids, then the ep. */
+int hnsw_import_points(hnsw_index *h, const float *rows, uint64_t n, const uint8_t *levels);
+int hnsw_import_layer(hnsw_index *h, uint32_t layer, uint64_t n_nodes, const uint32_t *node_ids,
+                      const uint64_t *offsets, const uint32_t *nbrs);
+
+/* ---- query (the hot path; HIP kernels) ------------------------------------------------------ */
+/* HNSW::ann_by_vector(&self, &Vec<f32>, n, ef) -> Result<Vec<NodeID>, String>, template.rs:306-335.
+ * ids[n]; *count = number of ids returned (< n when ef < n or the index is tiny). */
+int hnsw_search(hnsw_index *h, const float *q, uint32_t n, uint32_t ef, uint32_t *ids,
+                uint32_t *count);
+/* Batched form (new; the reference answers one query per call): Q is nq x dim host memory,
+ * ids nq x n (pad UINT32_MAX), dists nq x n or NULL (the distances the reference discards, pad
+ * +inf), counts nq or NULL, stats nq or NULL.  Returns the first per-query error, if any. */
+int hnsw_search_batch(hnsw_index *h, const float *Q, uint64_t nq, uint32_t n, uint32_t ef,
+                      uint32_t *ids, float *dists, uint32_t *counts, hnsw_query_stats *stats);
+/* Same with every buffer already resident in HBM on the handle's device; enqueues on `stream`
+ * (a hipStream_t, NULL = default stream) and returns without synchronising.  d_stats is
+ * required (its status field carries per-query errors); d_dists / d_counts may be NULL. */
+int hnsw_search_batch_device(hnsw_index *h, const float *d_Q, uint64_t nq, uint32_t n, uint32_t ef,
+                             uint32_t *d_ids, float *d_dists, uint32_t *d_counts,
+                             hnsw_query_stats *d_stats, void *stream);
+
+/* Test seams that mirror the reference's own units:
+ * VecBase::dist2many (vectors/src/lib.rs:17-22): the query (quantised like ann_by_vector does,
+ * template.rs:313) against stored ids, on the device, exact accumulation order. */
+int hnsw_distance_batch(hnsw_index *h, const float *q, const uint32_t *ids, uint64_t k, float *out);
+/* Searcher::search_layer (searcher.rs:23-103) on one layer from an explicit entry set. */
+int hnsw_search_layer(hnsw_index *h, uint32_t layer, const float *q, const uint32_t *entry_ids,
+                      uint32_t n_entry, uint32_t ef, uint32_t *out_ids, float *out_dists,
+                      uint32_t *out_count, hnsw_query_stats *stats);
+/* Exact top-k under the index's own metric by exhaustive scan on the device (the reference's
+ * brute force: helpers/glove.rs:94-109, template.rs:531-541). */
+int hnsw_brute_force(hnsw_index *h, const float *Q, uint64_t nq, uint32_t k, uint32_t *ids,
+                     float *dists);
+
+/* ---- accessors ----------------------------------------------------------------------------- */
+uint64_t hnsw_len(const hnsw_index *h);                                   /* template.rs:146 */
+/* HNSW::distance(a, b) -> Option<f32>, template.rs:150-152: HNSW_ERR_ARG stands for None */
+int hnsw_distance(const hnsw_index *h, uint32_t a, uint32_t b, float *out);
+/* get_point(id).get_vals(): the (dequantised) values, template.rs:154, vectors/src/lib.rs:24-26 */
+int hnsw_get_vector(const hnsw_index *h, uint32_t id, float *out);
+int hnsw_get_level(const hnsw_index *h, uint32_t id, uint32_t *out);
+/* raw QuantVec fields (vectors/src/quant.rs:6-11); HNSW_ERR_ARG for an F32 index */
+int hnsw_get_quant(const hnsw_index *h, uint32_t id, uint8_t *codes, float *min_out, float *delta_out);
+uint32_t hnsw_layer_count(const hnsw_index *h);                           /* layers.rs:21-23 */
+uint64_t hnsw_layer_nb_nodes(const hnsw_index *h, uint32_t layer);        /* graph.rs:157-159 */
+uint32_t hnsw_layer_m(const hnsw_index *h, uint32_t layer);               /* Graph.m, layers.rs:50 */
+/* Graph::iter_nodes (graph.rs:27-29), ascending id; *n receives the node count */
+int hnsw_layer_nodes(const hnsw_index *h, uint32_t layer, uint32_t *out, uint64_t cap, uint64_t *n);
+/* Graph::neighbors / neighbors_vec / degree (graph.rs:96-113,150-155), ascending id */
+int hnsw_neighbors(const hnsw_index *h, uint32_t layer, uint32_t id, uint32_t *buf, uint32_t cap,
+                   uint32_t *deg);
+/* whole layer as CSR over ascending node ids: node_ids[n_nodes], offsets[n_nodes + 1], nbrs[nnz];
+ * pass NULL buffers to query the sizes. */
+int hnsw_export_layer(const hnsw_index *h, uint32_t layer, uint32_t *node_ids, uint64_t *offsets,
+                      uint32_t *nbrs, uint64_t *n_nodes, uint64_t *nnz);
+/* HNSW::assert_param_compliance, template.rs:341-370: *ok = 1 when every degree <= ceil(1.1 *
+ * limit) and no node of a multi-node layer is isolated */
+int hnsw_check_param_compliance(const hnsw_index *h, int *ok);
+
+/* ---- persistence ---------------------------------------------------------------------------- */
+/* HNSW::save / HNSW::load, template.rs:43-131: directory with `points`, `params`, `layers/<n>`,
+ * all big-endian, byte-compatible with the reference's Serializer impls (params.rs:78-114,
+ * points.rs:124-145, point.rs:57-75, quant.rs:102-124, graph.rs:168-251). */
+int hnsw_save(const hnsw_index *h, const char *dir);
+int hnsw_load(const char *dir, hnsw_index **out);
+
+/* ---- device management ---------------------------------------------------------------------- */
+int hnsw_device_count(int *count);
+/* bind the handle to a HIP device (default: the current device at first upload) */
+int hnsw_set_device(hnsw_index *h, int device);
+/* make the HBM snapshot current now (otherwise done lazily by the first search after a mutation) */
+int hnsw_upload(hnsw_index *h);
+int hnsw_device_bytes(const hnsw_index *h, uint64_t *bytes);
+
+/* ---- harness helpers (not part of the reference's API) --------------------------------------- */
+/* Synthetic "GloVe-shaped" data, counter-based so any row can be generated independently:
+ * recipe 0 = low intrinsic dimension clusters (A), 1 = isotropic mixture (B), 2 = U[0,1)
+ * (the reference's make_rand_vectors, template.rs:630-638).  out is n x d. */
+int hnsw_synth_rows(int recipe, uint64_t seed, uint64_t first_row, uint64_t n, uint32_t d, float *out,
+                    uint32_t nb_threads);
+/* the level sampler used when levels are not given: believed-equivalent restatement of rand
+ * 0.8.5 StdRng::seed_from_u64(0) -> gen::<f32>() -> floor(-ln(r) * ml) (points.rs:39-48,148-160) */
+int hnsw_draw_levels(uint32_t m, uint64_t n, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
