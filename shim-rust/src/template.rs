@@ -1,0 +1,253 @@
+//! `hnsw::template::HNSW` on libhnsw_mi355x.so -- the reference API of hnsw/src/template.rs.
+//!
+//! Error mapping: the C ABI never unwinds.  Where the reference returns `Err(String)` the shim
+//! returns `Err(hnsw_last_error())`; where it panics (dimension mismatch template.rs:253-262, NaN
+//! distance graph/src/dist.rs:32, save I/O template.rs:45-71) the shim panics with the same text.
+use std::ffi::CString;
+use std::path::Path;
+use std::ptr;
+
+use crate::ffi::*;
+use crate::params::{NodeID, Params};
+
+pub struct HNSW {
+    handle: *mut HnswIndex,
+    /// public field in the reference (template.rs:37); refreshed after every mutating call
+    pub params: Params,
+}
+
+// `ann_by_vector(&self)` is re-entrant in the reference; the native search is too
+unsafe impl Send for HNSW {}
+unsafe impl Sync for HNSW {}
+
+/// What `get_point(id)` hands out (points/src/point.rs:6-10); `get_vals` is VecBase::get_vals.
+pub struct Point {
+    pub id: NodeID,
+    pub level: u8,
+    vals: Vec<f32>,
+}
+impl Point {
+    pub fn get_vals(&self) -> Vec<f32> {
+        self.vals.clone()
+    }
+}
+
+/// Read-only view of a layer (graph/src/graph.rs:9-16)
+pub struct Graph<'a> {
+    index: &'a HNSW,
+    pub level: usize,
+    pub m: usize,
+}
+impl<'a> Graph<'a> {
+    pub fn nb_nodes(&self) -> usize {
+        unsafe { hnsw_layer_nb_nodes(self.index.handle, self.level as u32) as usize }
+    }
+    pub fn iter_nodes(&self) -> impl Iterator<Item = NodeID> {
+        let n = self.nb_nodes();
+        let mut out = vec![0u32; n.max(1)];
+        let mut cnt = 0u64;
+        unsafe { hnsw_layer_nodes(self.index.handle, self.level as u32, out.as_mut_ptr(), n as u64, &mut cnt) };
+        out.truncate(n);
+        out.into_iter()
+    }
+    pub fn neighbors(&self, node: NodeID) -> Result<std::collections::HashSet<NodeID>, String> {
+        let mut buf = vec![0u32; 4096];
+        let mut deg = 0u32;
+        let rc = unsafe {
+            hnsw_neighbors(self.index.handle, self.level as u32, node, buf.as_mut_ptr(), 4096, &mut deg)
+        };
+        if rc != HNSW_OK {
+            return Err(last_error()); // GraphError::NodeNotInGraph
+        }
+        buf.truncate(deg as usize);
+        Ok(buf.into_iter().collect())
+    }
+    pub fn degree(&self, node: NodeID) -> Result<usize, String> {
+        let mut deg = 0u32;
+        let rc = unsafe { hnsw_neighbors(self.index.handle, self.level as u32, node, ptr::null_mut(), 0, &mut deg) };
+        if rc != HNSW_OK {
+            Err(last_error())
+        } else {
+            Ok(deg as usize)
+        }
+    }
+}
+
+impl HNSW {
+    fn refresh_params(&mut self) {
+        let mut p = HnswParams::default();
+        unsafe { hnsw_get_params(self.handle, &mut p) };
+        self.params = Params {
+            ep: p.ep,
+            m: p.m as usize,
+            mmax: p.mmax as usize,
+            mmax0: p.mmax0 as usize,
+            ml: p.ml,
+            ef_cons: p.ef_cons as usize,
+            dim: p.dim as usize,
+        };
+    }
+
+    fn from_handle(handle: *mut HnswIndex) -> Self {
+        let mut s = HNSW {
+            handle,
+            params: Params { ep: 0, m: 0, mmax: 0, mmax0: 0, ml: 0.0, ef_cons: 0, dim: 0 },
+        };
+        s.refresh_params();
+        s
+    }
+
+    /// template.rs:133-144
+    pub fn new(m: usize, ef_cons: Option<usize>, dim: usize) -> Self {
+        let mut h = ptr::null_mut();
+        let rc = unsafe { hnsw_create(m as u32, ef_cons.unwrap_or(0) as u32, dim as u32, HNSW_VEC_QUANT8, &mut h) };
+        assert_eq!(rc, HNSW_OK, "{}", last_error());
+        Self::from_handle(h)
+    }
+
+    /// template.rs:388-444 (consumes and returns the index)
+    pub fn insert_bulk(mut self, vectors: Vec<Vec<f32>>, nb_threads: usize, verbose: bool) -> Result<HNSW, String> {
+        let dim = self.params.dim;
+        let mut flat = Vec::with_capacity(vectors.len() * dim);
+        for v in vectors.iter() {
+            if v.len() != dim {
+                // check_points_dim, template.rs:253-262
+                panic!("The current index dimension is {0}, but tried inserting points of dimension {1}", dim, v.len());
+            }
+            flat.extend_from_slice(v);
+        }
+        let rc = unsafe {
+            hnsw_insert_bulk(self.handle, flat.as_ptr(), vectors.len() as u64, nb_threads as u32, verbose as i32)
+        };
+        self.refresh_params();
+        match rc {
+            HNSW_OK => Ok(self),
+            HNSW_ERR_NAN_INPUT | HNSW_ERR_BAD_DIM => panic!("{}", last_error()),
+            _ => Err(last_error()),
+        }
+    }
+
+    /// template.rs:165-173
+    pub fn insert_vec(&mut self, vector: &Vec<f32>) -> Result<NodeID, String> {
+        if vector.len() != self.params.dim {
+            panic!("The current index dimension is {0}, but tried inserting points of dimension {1}", self.params.dim, vector.len());
+        }
+        let mut id = 0u32;
+        let rc = unsafe { hnsw_insert_vec(self.handle, vector.as_ptr(), &mut id) };
+        self.refresh_params();
+        match rc {
+            HNSW_OK => Ok(id),
+            HNSW_ERR_NAN_INPUT => panic!("{}", last_error()),
+            _ => Err(last_error()),
+        }
+    }
+
+    /// template.rs:306-335 -- one query per call, ids only, fewer than n when ef < n
+    pub fn ann_by_vector(&self, vector: &Vec<f32>, n: usize, ef: usize) -> Result<Vec<NodeID>, String> {
+        assert_eq!(vector.len(), self.params.dim, "query dimension"); // stricter than the reference (Q4)
+        let mut ids = vec![0u32; n.max(1)];
+        let mut count = 0u32;
+        let rc = unsafe { hnsw_search(self.handle, vector.as_ptr(), n as u32, ef as u32, ids.as_mut_ptr(), &mut count) };
+        match rc {
+            HNSW_OK => {
+                ids.truncate(count as usize);
+                Ok(ids)
+            }
+            HNSW_ERR_NAN_INPUT => panic!("{}", last_error()), // Dist::cmp unwrap, graph/src/dist.rs:32
+            _ => Err(last_error()),
+        }
+    }
+
+    /// New: the batched GPU entry point (`nq` queries, row-major), ids padded with u32::MAX
+    pub fn ann_by_vectors(&self, queries: &[f32], n: usize, ef: usize) -> Result<(Vec<NodeID>, Vec<f32>), String> {
+        let nq = queries.len() / self.params.dim;
+        let mut ids = vec![u32::MAX; nq * n];
+        let mut dists = vec![f32::INFINITY; nq * n];
+        let rc = unsafe {
+            hnsw_search_batch(self.handle, queries.as_ptr(), nq as u64, n as u32, ef as u32, ids.as_mut_ptr(),
+                              dists.as_mut_ptr(), ptr::null_mut(), ptr::null_mut())
+        };
+        if rc != HNSW_OK {
+            return Err(last_error());
+        }
+        Ok((ids, dists))
+    }
+
+    pub fn len(&self) -> usize {
+        unsafe { hnsw_len(self.handle) as usize } // template.rs:146
+    }
+
+    pub fn distance(&self, a: NodeID, b: NodeID) -> Option<f32> {
+        let mut d = 0f32; // template.rs:150-152
+        if unsafe { hnsw_distance(self.handle, a, b, &mut d) } == HNSW_OK { Some(d) } else { None }
+    }
+
+    pub fn get_point(&self, point_id: NodeID) -> Option<Point> {
+        let mut vals = vec![0f32; self.params.dim]; // template.rs:154-156
+        let mut level = 0u32;
+        unsafe {
+            if hnsw_get_vector(self.handle, point_id, vals.as_mut_ptr()) != HNSW_OK {
+                return None;
+            }
+            hnsw_get_level(self.handle, point_id, &mut level);
+        }
+        Some(Point { id: point_id, level: level as u8, vals })
+    }
+
+    pub fn get_layer(&self, layer_nb: usize) -> Graph<'_> {
+        let n = unsafe { hnsw_layer_count(self.handle) } as usize; // template.rs:192-194
+        if layer_nb >= n {
+            panic!("Layer {layer_nb} not found in the structure."); // layers.rs:25-30
+        }
+        Graph { index: self, level: layer_nb, m: unsafe { hnsw_layer_m(self.handle, layer_nb as u32) } as usize }
+    }
+
+    pub fn assert_param_compliance(&self) {
+        let mut ok = 0;
+        unsafe { hnsw_check_param_compliance(self.handle, &mut ok) };
+        if ok != 0 {
+            println!("Index complies with params.") // template.rs:367-369
+        }
+    }
+
+    /// template.rs:43-73 (panics on I/O errors like the reference)
+    pub fn save(&self, dir: &Path) {
+        let c = CString::new(dir.to_str().expect("utf-8 path")).unwrap();
+        let rc = unsafe { hnsw_save(self.handle, c.as_ptr()) };
+        if rc != HNSW_OK {
+            panic!("{}", last_error());
+        }
+    }
+
+    /// template.rs:75-131
+    pub fn load(dir: &Path) -> Result<Self, String> {
+        let c = CString::new(dir.to_str().ok_or("non utf-8 path")?).map_err(|e| e.to_string())?;
+        let mut h = ptr::null_mut();
+        let rc = unsafe { hnsw_load(c.as_ptr(), &mut h) };
+        if rc != HNSW_OK {
+            return Err(last_error());
+        }
+        Ok(Self::from_handle(h))
+    }
+}
+
+impl Clone for HNSW {
+    fn clone(&self) -> Self {
+        let mut h = ptr::null_mut(); // #[derive(Clone)], template.rs:35
+        let rc = unsafe { hnsw_clone(self.handle, &mut h) };
+        assert_eq!(rc, HNSW_OK, "{}", last_error());
+        Self::from_handle(h)
+    }
+}
+
+impl Drop for HNSW {
+    fn drop(&mut self) {
+        unsafe { hnsw_free(self.handle) }
+    }
+}
+
+impl std::fmt::Debug for HNSW {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        f.debug_struct("HNSW").field("params", &self.params).field("len", &self.len()).finish()
+    }
+}

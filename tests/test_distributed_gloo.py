@@ -1,0 +1,72 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the query sharding plumbing
+(hnsw_rs_amd/distributed.py).  The local search is the CPU oracle here (tests may use it); on the
+GPU box the same ShardedSearcher wraps the HIP search and runs over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nq, outfile):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hnsw_rs_amd.distributed import ShardedSearcher, shard_bounds
+    from oracle import oracle_py as O
+    from tests.util import rand_vectors
+    n, d, m, k, ef = 800, 12, 8, 5, 20
+    vs = rand_vectors(n, d, 1)
+    orc = O.OracleHNSW(m, None, d).insert_bulk(vs, O.draw_levels(n, m, 1))  # every rank: same replica
+
+    def local_search(Q):
+        ids, dists, _, _ = orc.search_batch(Q.numpy(), k, ef)
+        return torch.from_numpy(ids.astype(np.int64)).to(torch.int32), torch.from_numpy(dists)
+
+    s = ShardedSearcher(local_search, d, k, torch.device("cpu"))
+    Q = torch.from_numpy(rand_vectors(nq, d, 2)) if rank == 0 else None
+    ids, dists = s.search(Q, nq)
+    lo, hi = shard_bounds(nq, world, rank)
+    assert 0 <= lo <= hi <= nq
+    if rank == 0:
+        w_ids, w_d, _, _ = orc.search_batch(Q.numpy(), k, ef)
+        ok = np.array_equal(ids.numpy().astype(np.uint32), w_ids) and np.array_equal(dists.numpy(), w_d)
+        open(outfile, "w").write("ok" if ok else "mismatch")
+    else:
+        assert ids is None and dists is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nq", [64, 37])  # 37: uneven split, the last shard is padded
+def test_query_sharding_world_size_2_gloo(tmp_path, nq):
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(2, _free_port(), nq, out), nprocs=2, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_shard_bounds_cover_the_batch():
+    from hnsw_rs_amd.distributed import shard_bounds, shard_size
+    for nq in (1, 7, 1024, 1025):
+        for w in (1, 2, 3, 8):
+            cover = []
+            for r in range(w):
+                lo, hi = shard_bounds(nq, w, r)
+                cover += list(range(lo, hi))
+                assert hi - lo <= shard_size(nq, w)
+            assert cover == list(range(nq))
