@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhnsw_mi355x.so")
+# HNSW_MI355X_LIB selects another build of the same library (e.g. the diagnostic stamps build)
+LIB_PATH = os.environ.get("HNSW_MI355X_LIB") or os.path.join(_HERE, "libhnsw_mi355x.so")
 
 VEC_QUANT8 = 0
 VEC_F32 = 1
@@ -86,6 +87,7 @@ SYMBOLS = {
     "hnsw_set_device": (C.c_int, [vp, C.c_int]),
     "hnsw_upload": (C.c_int, [vp]),
     "hnsw_device_bytes": (C.c_int, [vp, u64p]),
+    "hnsw_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
     "hnsw_synth_rows": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, f32p, C.c_uint32]),
     "hnsw_draw_levels": (C.c_int, [C.c_uint32, C.c_uint64, u8p]),
 }

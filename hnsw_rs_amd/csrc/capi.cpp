@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -283,6 +284,9 @@ int hnsw_search_batch_device(hnsw_index *h, const float *d_Q, uint64_t nq, uint3
     rc = ensure_uploaded(h);
     if (rc != HNSW_OK) return rc;
     hx::SearchArgs a = ann_args(h->dev.view, d_Q, n, ef, d_ids, d_dists, d_counts, d_stats);
+#ifdef HX_STAMPS
+    a.dbg = reinterpret_cast<unsigned long long *>(getenv("HX_DBG_PTR") ? strtoull(getenv("HX_DBG_PTR"), nullptr, 0) : 0);
+#endif
     return hx::launch_search(h->dev.view, a, (uint32_t)nq, 0, static_cast<hipStream_t>(stream));
 }
 
@@ -547,6 +551,20 @@ int hnsw_set_device(hnsw_index *h, int device) {
 int hnsw_upload(hnsw_index *h) {
     if (!h) return HNSW_ERR_ARG;
     return ensure_uploaded(h);
+}
+int hnsw_set_option(hnsw_index *h, const char *key, int64_t value) {
+    if (!h || !key) return HNSW_ERR_ARG;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!strcmp(key, "inline_rows")) {
+        h->dev.inline_rows = (int)value;
+    } else if (!strcmp(key, "inline_budget_mb")) {
+        h->dev.fat_budget_bytes = (uint64_t)value << 20;
+    } else {
+        set_error("unknown option %s", key);
+        return HNSW_ERR_ARG;
+    }
+    h->dev.release();  // rebuilt by the next upload
+    return HNSW_OK;
 }
 int hnsw_device_bytes(const hnsw_index *h, uint64_t *bytes) {
     if (!h || !bytes) return HNSW_ERR_ARG;

@@ -4,6 +4,8 @@
 #include "device_index.h"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -162,18 +164,55 @@ int DeviceIndex::upload(const HostIndex &idx, int dev) {
     std::vector<uint32_t> ub(idx.upper_base.begin(), idx.upper_base.end());
     ub.resize(N, UINT32_MAX);
 
+    // ---- inline rows ("fat" layer-0 blocks), see device_index.h ----
+    std::vector<uint8_t> fat;
+    {
+        int want = inline_rows;
+        if (const char *e = getenv("HNSW_MI355X_INLINE_ROWS")) want = atoi(e);
+        const uint32_t used = 8 + v.nch4 + v.rem;
+        const bool room = idx.kind == HNSW_VEC_QUANT8 && v.S0 == 32 && v.half_bytes >= used + 4;
+        const uint64_t need = (uint64_t)N * v.S0 * v.row_stride;
+        if (room && (want == 1 || (want < 0 && need <= fat_budget_bytes))) {
+            v.fat_stride = (uint64_t)v.S0 * v.row_stride;
+            fat.assign(need, 0);
+            const uint32_t idpos = v.half_bytes - 4;
+            parallel_rows(N, [&](uint64_t lo, uint64_t hi) {
+                for (uint64_t i = lo; i < hi; i++) {
+                    for (uint32_t k = 0; k < v.S0; k++) {
+                        const uint32_t nb = adj0[i * v.S0 + k];
+                        uint8_t *o = &fat[i * v.fat_stride + (uint64_t)k * v.row_stride];
+                        if (nb != HX_EMPTY_SLOT && !(nb & HX_OVF_FLAG))
+                            memcpy(o, &rows[(size_t)nb * v.row_stride], v.row_stride);
+                        memcpy(o + idpos, &nb, 4);
+                    }
+                }
+            });
+        }
+    }
+
     struct Up {
         const void *src;
         size_t nbytes;
-    } ups[6] = {{rows.data(), rows.size()},
+    } ups[7] = {{rows.data(), rows.size()},
                 {adj0.data(), adj0.size() * 4},
                 {adj_up.data(), adj_up.size() * 4},
                 {ub.data(), ub.size() * 4},
                 {ovf_off.data(), ovf_off.size() * 4},
-                {ovf_nbrs.data(), ovf_nbrs.size() * 4}};
+                {ovf_nbrs.data(), ovf_nbrs.size() * 4},
+                {fat.data(), fat.size()}};
     bytes = 0;
-    for (int i = 0; i < 6; i++) {
-        HIP_TRY(hipMalloc(&bufs_[i], ups[i].nbytes));
+    for (int i = 0; i < 7; i++) {
+        if (ups[i].nbytes == 0) continue;
+        if (i == 6) {  // the inline-rows copy is optional: without room for it the compact path serves
+            if (hipMalloc(&bufs_[i], ups[i].nbytes) != hipSuccess) {
+                (void)hipGetLastError();
+                bufs_[i] = nullptr;
+                v.fat_stride = 0;
+                continue;
+            }
+        } else {
+            HIP_TRY(hipMalloc(&bufs_[i], ups[i].nbytes));
+        }
         HIP_TRY(hipMemcpy(bufs_[i], ups[i].src, ups[i].nbytes, hipMemcpyHostToDevice));
         bytes += ups[i].nbytes;
     }
@@ -183,6 +222,7 @@ int DeviceIndex::upload(const HostIndex &idx, int dev) {
     v.upper_base = (const uint32_t *)bufs_[3];
     v.ovf_off = (const uint32_t *)bufs_[4];
     v.ovf_nbrs = (const uint32_t *)bufs_[5];
+    v.fat = (const uint8_t *)bufs_[6];
     view = v;
     version_seen = idx.version;
     valid = true;

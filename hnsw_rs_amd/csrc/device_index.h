@@ -17,6 +17,14 @@
 //   adj_up    upper-layer rows, S1 = pow2 >= max(m, 8) slots each; the rows of one node for
 //             layers 1..level are contiguous: row(id, l) = upper_base[id] + l - 1.
 //   upper_base N u32 (0xFFFFFFFF for level-0 nodes).
+//   fat       (optional, "inline rows") layer-0 blocks of S0 x row_stride bytes, one per node: slot k
+//             of node i holds a COPY of the vector row of its k-th neighbour with that neighbour's
+//             id in the last 4 (padding) bytes of half 0.  One expansion then costs ONE dependent,
+//             fully coalesced 4-KiB read (m = 16, d = 100) instead of an adjacency row followed by
+//             a 32-row gather, and the block of the predicted next candidate can be prefetched
+//             while the current one is evaluated.  Costs S0 x the row bytes in HBM (4.1 GB per 1M
+//             points at d = 100 -- the card has 288 GB); built when it fits the configured budget,
+//             otherwise the compact rows + adj0 path is used.  Empty slots: id 0xFFFFFFFF.
 //   ovf_off / ovf_nbrs  CSR of the neighbours that do not fit a row (degree > S happens:
 //             SURVEY.md H6).  Such a row keeps S - 1 ids and its last slot holds
 //             0x80000000 | overflow row.  Node ids are < 2^31 (enforced by the host index).
@@ -40,6 +48,8 @@ struct DevView {  // kernel argument, passed by value
     const uint32_t *upper_base;
     const uint32_t *ovf_off;
     const uint32_t *ovf_nbrs;
+    const uint8_t *fat;   // inline-rows blocks of layer 0, or null
+    uint64_t fat_stride;  // bytes per node block = S0 * row_stride
     uint32_t row_stride;  // bytes
     uint32_t half_bytes;  // QUANT8: bytes per half row
     uint32_t S0, S1;      // slots per adjacency row (powers of two)
@@ -62,12 +72,16 @@ struct SearchArgs {
     float *out_dists;            // nq x n or null
     uint32_t *out_counts;        // nq or null
     hnsw_query_stats *out_stats; // nq
+    unsigned long long *dbg;     // diagnostic builds only (HX_STAMPS): nq x 6 cycle sums, else null
 };
 
 class DeviceIndex {
   public:
     ~DeviceIndex() { release(); }
     int upload(const HostIndex &idx, int device);
+    // inline-rows layout: -1 = auto (build it when it fits fat_budget_bytes), 0 = never, 1 = always
+    int inline_rows = -1;
+    uint64_t fat_budget_bytes = 64ull << 30;
     void release();
     bool current(const HostIndex &idx) const { return valid && version_seen == idx.version; }
 
@@ -78,7 +92,7 @@ class DeviceIndex {
     DevView view{};
 
   private:
-    void *bufs_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void *bufs_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 // row packing helpers shared by upload and tests

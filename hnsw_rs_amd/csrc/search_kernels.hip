@@ -46,6 +46,16 @@ static constexpr u64 KEY_EXPANDED = 1ull << 63;
 
 #define HX_MAX_R 8  // ef <= 64 * HX_MAX_R
 
+// Diagnostic build only (make stamps): per-phase cycle shares of the inline-rows expansion loop,
+// written to a side buffer nothing else reads.  The shipped library is built without HX_STAMPS.
+#ifdef HX_STAMPS
+#define STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#define STAMP_ADD(slot, a, b) dbg_acc[slot] += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(slot, a, b)
+#endif
+
 __device__ __forceinline__ u64 readlane64(u64 v, int l) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
@@ -261,6 +271,26 @@ __device__ __forceinline__ float dist_any_dim(const DevView &v, uint32_t id, boo
     }
 }
 
+// Asynchronous global -> LDS copy of one 1-KiB piece (64 lanes x 16 bytes): lane l's 16 bytes at
+// `gsrc` land at LDS byte address lds_dst + 16 l.  No VGPR destination, and -- being inline asm --
+// not part of the compiler's s_waitcnt bookkeeping, so the copy stays in flight across the loops
+// and LDS atomics of the expansion body (hipcc drains vmcnt(0) at every loop it cannot see
+// through).  The consumer issues its own `s_waitcnt vmcnt(0)` before reading the bytes back
+// (cdna_hip_programming.md section 5.7: M0 is written in the same statement that reads it).
+__device__ __forceinline__ void dma_piece_to_lds(const void *gsrc, uint32_t lds_dst) {
+    lds_dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst);  // provably wave-uniform
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
 // LDS-resident query values of one half
 struct QLds {
     const float *p;
@@ -290,6 +320,43 @@ struct WaveList {
         u64 smask = __ballot(surv);
         if (smask == 0) return;
         const uint32_t m = (uint32_t)__popcll(smask);
+        if (m <= 4) {
+            // few survivors (the usual case once the list is full): insert them one at a time by
+            // shifting the tail of the register-resident list one lane to the right (DPP
+            // wave_shr:1, no LDS round trip).  Insertion order is irrelevant (N2).
+            u64 it = smask;
+            while (it) {
+                const int j = __ffsll((long long)it) - 1;
+                it &= it - 1;
+                const u64 e = readlane64(key, j);
+                if (n_cur >= ef && !(e < last_key)) continue;  // an earlier insert tightened the bound
+                uint32_t pos = 0;
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    pos += (uint32_t)__popcll(__ballot((L[r] & KEY_MASK) < e));
+                u64 carry = 0;  // lane 63 of the previous register feeds lane 0 of the next
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const uint32_t idx = 64u * r + lane;
+                    const uint32_t lo = (uint32_t)L[r], hi = (uint32_t)(L[r] >> 32);
+                    uint32_t slo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x138, 0xF, 0xF, false);
+                    uint32_t shi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x138, 0xF, 0xF, false);
+                    u64 sh = ((u64)shi << 32) | slo;
+                    if (lane == 0) sh = carry;
+                    if (R > 1) carry = readlane64(L[r], 63);
+                    if (idx == pos)
+                        L[r] = e;
+                    else if (idx > pos)
+                        L[r] = sh;
+                }
+                n_cur = min(n_cur + 1, ef);
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    if (64u * r + lane >= n_cur) L[r] = KEY_INVALID;
+                refresh_last(ef);
+            }
+            return;
+        }
         uint32_t shift[R];
 #pragma unroll
         for (int r = 0; r < R; r++) shift[r] = 0;
@@ -353,20 +420,40 @@ struct WaveList {
     }
 };
 
-// LDS visited table: open addressing, linear probing, key = node id, empty = 0xFFFFFFFF.
-// Returns true when id was not present (IntSet::insert, results.rs:101-103).
+// LDS visited table (IntSet::insert, results.rs:101-103): open addressing over BUCKETS of four
+// 32-bit slots.  One ds_read_b128 fetches the home bucket, the four compares run in registers and
+// a single ds_cmpst claims the first empty slot, so an insert is two LDS round trips whatever the
+// load; the classic one-slot linear probe needed one round trip per probe and the wave iterated as
+// long as its unluckiest lane (4-5 rounds at 30 % load).  Slots fill left to right and never empty,
+// ids within one adjacency row are distinct, so "absent from the bucket, first empty slot claimed"
+// is an exact insert.  Returns true when id was not present.
 __device__ __forceinline__ bool visited_insert(uint32_t *tab, uint32_t hmask, uint32_t slots_log2,
                                                uint32_t id) {
-    uint32_t s = (id * 0x9E3779B1u) >> (32 - slots_log2);
+    const uint32_t bmask = hmask >> 2;
+    uint32_t b = (id * 0x9E3779B1u) >> (32 - (slots_log2 - 2));
     while (true) {
-        const uint32_t old = atomicCAS(&tab[s], HX_EMPTY_SLOT, id);
+        const uint4 bk = *reinterpret_cast<const uint4 *>(tab + 4 * b);
+        if (bk.x == id || bk.y == id || bk.z == id || bk.w == id) return false;
+        int j = -1;
+        if (bk.x == HX_EMPTY_SLOT)
+            j = 0;
+        else if (bk.y == HX_EMPTY_SLOT)
+            j = 1;
+        else if (bk.z == HX_EMPTY_SLOT)
+            j = 2;
+        else if (bk.w == HX_EMPTY_SLOT)
+            j = 3;
+        if (j < 0) {
+            b = (b + 1) & bmask;  // bucket full: next bucket
+            continue;
+        }
+        const uint32_t old = atomicCAS(&tab[4 * b + j], HX_EMPTY_SLOT, id);
         if (old == HX_EMPTY_SLOT) return true;
-        if (old == id) return false;
-        s = (s + 1) & hmask;
+        // another lane of this wave took that slot in the same round: look at the bucket again
     }
 }
 
-template <int KIND, int P, int DS, int R>
+template <int KIND, int P, int DS, int R, bool FAT>
 __global__ void __launch_bounds__(64)
 hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -377,6 +464,11 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
     u64 *perm = reinterpret_cast<u64 *>(smem + 4ull * hslots);
     float *yq = reinterpret_cast<float *>(perm + 64 * R);
     const uint32_t vis_limit = hslots - (hslots >> 2);  // 75 % load at most
+    // FAT: two 64 x 16 x P byte buffers for the prefetched block (after yq, 16-byte aligned)
+    const uint32_t yq_bytes =
+        ((KIND == HNSW_VEC_QUANT8 ? 2u * (v.half_bytes - 8) * 4u : v.dim * 4u) + 15u) & ~15u;
+    unsigned char *spec_buf = reinterpret_cast<unsigned char *>(yq) + yq_bytes;
+    const uint32_t spec_lds = __builtin_amdgcn_groupstaticsize() + 4u * hslots + 64u * R * 8u + yq_bytes;
 
     constexpr int LPC = (KIND == HNSW_VEC_QUANT8) ? 2 : 1;  // lanes per candidate
     constexpr int CHUNK = 64 / LPC;                         // adjacency slots per pass
@@ -387,6 +479,10 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
     const float *qv = a.Q + (size_t)q * d;
     uint32_t n_dist = 0, n_exp = 0, sum_deg = 0;
     int32_t status = HNSW_OK;
+#ifdef HX_STAMPS
+    unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
 
     // ---- stage the query (Point::new -> QuantVec::new for QUANT8, template.rs:313) ----
     const uint32_t nq_half = (KIND == HNSW_VEC_QUANT8) ? (v.half_bytes - 8) : 0;
@@ -488,7 +584,9 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
     for (int layer = a.layer_hi; status == HNSW_OK && layer >= a.layer_lo; layer--) {
         const uint32_t ef_l = max(1u, layer > a.layer_lo ? a.ef_upper : a.ef_bottom);
         // visited.clear() (searcher.rs:101) / fresh Results: empty table
-        for (uint32_t s = lane; s < hslots; s += 64) htab[s] = HX_EMPTY_SLOT;
+        for (uint32_t s = lane; s < (hslots >> 2); s += 64)
+            reinterpret_cast<uint4 *>(htab)[s] =
+                make_uint4(HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT);
         __syncthreads();
         n_vis = 0;
         // candidates ∪= selected, visited ∪= ids(selected)  (searcher.rs:32-33)
@@ -503,6 +601,167 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
         n_vis = wl.n_cur;
         wl.refresh_last(ef_l);
         const uint32_t S = layer == 0 ? v.S0 : v.S1;
+
+        if (FAT && layer == 0) {
+            // ---- layer 0 over the inline-rows blocks: ONE dependent, coalesced read per expansion
+            // (the 32 neighbour rows of the candidate, ids embedded), and the block of the PREDICTED
+            // next candidate -- the smallest unexpanded entry once the current one is marked -- is
+            // already in flight while the current block is filtered, evaluated and merged.  The
+            // prediction is a prefetch only: what is evaluated and merged, and in which order, is
+            // exactly what the loop below does on the compact layout.
+            constexpr int PP = P > 0 ? P : 1;
+            constexpr uint32_t BLK = 1024u * PP;  // bytes of one block image in LDS
+            uint4 w[PP];
+            bool have_spec = false;
+            uint32_t spec_id = 0, spec_sel = 0;
+            const size_t lane_off = (size_t)cslot * v.row_stride + (size_t)h * v.half_bytes;
+            while (true) {
+                STAMP(t0);
+                const int cpos = wl.first_unexpanded(lane);
+                if (cpos < 0) break;
+                uint32_t cid = 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if ((cpos >> 6) == r) {
+                        cid = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wl.L[r], cpos & 63);
+                        if (lane == (cpos & 63)) wl.L[r] |= KEY_EXPANDED;
+                    }
+                }
+                n_exp++;
+#ifdef HX_STAMPS
+                const bool dbg_hit = have_spec && spec_id == cid;
+                if (dbg_hit) dbg_acc[6]++;
+#endif
+                // Every block is staged through LDS by DMA (no compiler-visible VMEM load in this
+                // loop, so hipcc inserts no vmcnt wait that would also drain the prefetch): the
+                // current block is either the image prefetched one expansion ago or is fetched now;
+                // then the predicted next block is started into the other buffer.
+                const bool hit = have_spec && spec_id == cid;
+                uint32_t cur_sel = spec_sel;
+                if (!hit) {
+                    cur_sel = spec_sel ^ 1u;  // a stale prefetch may still be landing in spec_sel
+                    const unsigned char *src = v.fat + (size_t)cid * v.fat_stride + lane_off;
+#pragma unroll
+                    for (int p = 0; p < PP; p++)
+                        dma_piece_to_lds(src + 16 * p, spec_lds + cur_sel * BLK + 1024u * p);
+                }
+                have_spec = false;
+                {
+                    const int ppos = wl.first_unexpanded(lane);
+                    if (ppos >= 0) {
+                        uint32_t pid = 0;
+#pragma unroll
+                        for (int r = 0; r < R; r++)
+                            if ((ppos >> 6) == r)
+                                pid = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wl.L[r], ppos & 63);
+                        spec_sel = cur_sel ^ 1u;
+                        const unsigned char *src = v.fat + (size_t)pid * v.fat_stride + lane_off;
+#pragma unroll
+                        for (int p = 0; p < PP; p++)
+                            dma_piece_to_lds(src + 16 * p, spec_lds + spec_sel * BLK + 1024u * p);
+                        spec_id = pid;
+                        have_spec = true;
+                    }
+                }
+                // the current block has landed once all but the PP youngest DMA pieces are done
+                if (have_spec)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                {
+                    const uint4 *img = reinterpret_cast<const uint4 *>(spec_buf + cur_sel * BLK) + lane;
+#pragma unroll
+                    for (int p = 0; p < PP; p++) w[p] = img[64 * p];
+                }
+                STAMP(t1);
+                STAMP_ADD(0, t0, t1);
+                // the neighbour id travels in the last 4 bytes of half 0
+                const uint32_t raw = w[PP - 1].w;
+                const uint32_t nb = h ? (uint32_t)pair_swap_i((int)raw) : raw;
+                const bool is_ptr = nb != HX_EMPTY_SLOT && (nb & HX_OVF_FLAG);
+                const bool valid = nb != HX_EMPTY_SLOT && !is_ptr;
+                uint32_t ovf = HX_EMPTY_SLOT;
+                const u64 pm = __ballot(is_ptr);
+                if (pm) ovf = (uint32_t)__builtin_amdgcn_readlane((int)nb, __ffsll((long long)pm) - 1) & ~HX_OVF_FLAG;
+                const uint32_t cnt = (uint32_t)__popcll(__ballot(valid && h == 0));
+                if (cnt != 0) {
+                    sum_deg += cnt;
+                    if (n_vis + cnt > vis_limit) {
+                        status = HNSW_ERR_OVERFLOW;
+                        break;
+                    }
+                    n_vis += cnt;
+                    bool f = false;
+                    if (valid && h == 0) f = visited_insert(htab, hmask, slots_log2, nb);
+                    const bool fresh = (pair_swap_i(f ? 1 : 0) | (f ? 1 : 0)) != 0;
+                    const u64 fm = __ballot(fresh && h == 0);
+                    STAMP(t2);
+#ifdef HX_STAMPS
+                    if (dbg_hit)
+                        dbg_acc[1] += t2 - t1;
+                    else
+                        dbg_acc[5] += t2 - t1;
+#endif
+                    if (fm != 0) {
+                        n_dist += (uint32_t)__popcll(fm);
+                        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if (fresh) {
+                            if (DS > 0)
+                                quant_half_sums<PP, DS>(w, qreg, h, v.nch4, v.rem, acc);
+                            else
+                                quant_half_sums<PP, 0>(w, qlds, h, v.nch4, v.rem, acc);
+                        }
+                        const float b0 = pair_swap(acc[0]), b1 = pair_swap(acc[1]),
+                                    b2 = pair_swap(acc[2]), b3 = pair_swap(acc[3]);
+                        float s = 0.0f;
+                        s += acc[0];
+                        s += acc[1];
+                        s += acc[2];
+                        s += acc[3];
+                        s += b0;
+                        s += b1;
+                        s += b2;
+                        s += b3;
+                        const float dist = __builtin_sqrtf(s);
+                        u64 key = KEY_INVALID;
+                        bool nan = false;
+                        if (fresh && h == 0) {
+                            nan = dist != dist;
+                            if (!nan) key = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | nb;
+                        }
+                        if (__ballot(nan)) {
+                            status = HNSW_ERR_NAN_INPUT;
+                            break;
+                        }
+                        STAMP(t3);
+                        STAMP_ADD(2, t2, t3);
+                        wl.merge(key, ef_l, perm, lane);
+                        STAMP(t4);
+                        STAMP_ADD(3, t3, t4);
+                    }
+                }
+                if (ovf != HX_EMPTY_SLOT) {  // degree > S0: the rest of the row, compact rows
+                    const uint32_t lo = v.ovf_off[ovf], hi = v.ovf_off[ovf + 1];
+                    for (uint32_t base = lo; base < hi; base += CHUNK) {
+                        const uint32_t i = base + cslot;
+                        const bool ov = i < hi;
+                        const uint32_t onb = ov ? v.ovf_nbrs[i] : HX_EMPTY_SLOT;
+                        const uint32_t ocnt = (uint32_t)__popcll(__ballot(ov && h == 0));
+                        sum_deg += ocnt;
+                        if (n_vis + ocnt > vis_limit) {
+                            status = HNSW_ERR_OVERFLOW;
+                            break;
+                        }
+                        n_vis += ocnt;
+                        process(onb, ov, true, ef_l);
+                        if (status != HNSW_OK) break;
+                    }
+                    have_spec = false;  // the list may have changed after the prediction was made
+                    if (status != HNSW_OK) break;
+                }
+            }
+            continue;
+        }
 
         while (true) {
             const int cpos = wl.first_unexpanded(lane);
@@ -587,6 +846,12 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
         a.out_ids[(size_t)q * a.n + idx] = HX_EMPTY_SLOT;
         if (a.out_dists) a.out_dists[(size_t)q * a.n + idx] = __builtin_inff();
     }
+#ifdef HX_STAMPS
+    if (lane == 0 && a.dbg) {
+        dbg_acc[4] = __builtin_readcyclecounter() - t_begin;
+        for (int i = 0; i < 8; i++) a.dbg[(size_t)q * 8 + i] = dbg_acc[i];
+    }
+#endif
     if (lane == 0) {
         if (a.out_counts) a.out_counts[q] = count;
         hnsw_query_stats st;
@@ -610,13 +875,14 @@ uint32_t default_slots_log2(uint32_t ef) {
 }
 uint32_t max_slots_log2(uint32_t) { return 15; }
 
-template <int KIND, int P, int DS, int R>
+template <int KIND, int P, int DS, int R, bool FAT>
 static int launch_one(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint32_t slots_log2,
                       hipStream_t stream) {
     const size_t yq_bytes =
         (KIND == HNSW_VEC_QUANT8) ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4;
     size_t lds = (4ull << slots_log2) + 64ull * R * 8 + ((yq_bytes + 15) & ~15ull);
-    auto kern = hx_search_kernel<KIND, P, DS, R>;
+    if (FAT) lds += 2ull * 1024 * (P > 0 ? P : 1);
+    auto kern = hx_search_kernel<KIND, P, DS, R, FAT>;
     if (lds > 160 * 1024) {
         set_error("search needs %zu bytes of LDS (> 160 KiB)", lds);
         return HNSW_ERR_ARG;
@@ -641,10 +907,18 @@ static int launch_one(const DevView &v, const SearchArgs &a, uint32_t nblocks, u
 template <int KIND, int P, int DS>
 static int launch_r(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint32_t slots_log2,
                     hipStream_t stream, uint32_t ef_max) {
-    if (ef_max <= 64) return launch_one<KIND, P, DS, 1>(v, a, nblocks, slots_log2, stream);
-    if (ef_max <= 128) return launch_one<KIND, P, DS, 2>(v, a, nblocks, slots_log2, stream);
-    if (ef_max <= 256) return launch_one<KIND, P, DS, 4>(v, a, nblocks, slots_log2, stream);
-    if (ef_max <= 512) return launch_one<KIND, P, DS, 8>(v, a, nblocks, slots_log2, stream);
+    // the inline-rows variant needs one pass to cover a whole layer-0 row
+    constexpr bool CAN_FAT = (KIND == HNSW_VEC_QUANT8 && P > 0);
+    if (CAN_FAT && v.fat != nullptr && v.S0 == 32 && a.layer_lo == 0) {
+        if (ef_max <= 64) return launch_one<KIND, P, DS, 1, CAN_FAT>(v, a, nblocks, slots_log2, stream);
+        if (ef_max <= 128) return launch_one<KIND, P, DS, 2, CAN_FAT>(v, a, nblocks, slots_log2, stream);
+        if (ef_max <= 256) return launch_one<KIND, P, DS, 4, CAN_FAT>(v, a, nblocks, slots_log2, stream);
+        if (ef_max <= 512) return launch_one<KIND, P, DS, 8, CAN_FAT>(v, a, nblocks, slots_log2, stream);
+    }
+    if (ef_max <= 64) return launch_one<KIND, P, DS, 1, false>(v, a, nblocks, slots_log2, stream);
+    if (ef_max <= 128) return launch_one<KIND, P, DS, 2, false>(v, a, nblocks, slots_log2, stream);
+    if (ef_max <= 256) return launch_one<KIND, P, DS, 4, false>(v, a, nblocks, slots_log2, stream);
+    if (ef_max <= 512) return launch_one<KIND, P, DS, 8, false>(v, a, nblocks, slots_log2, stream);
     set_error("ef = %u is above the supported maximum of %d", ef_max, 64 * HX_MAX_R);
     return HNSW_ERR_ARG;
 }

@@ -295,6 +295,9 @@ class HNSW:
     def set_device(self, device):
         check(self._L.hnsw_set_device(self._h, int(device)))
 
+    def set_option(self, key, value):
+        check(self._L.hnsw_set_option(self._h, key.encode(), int(value)))
+
     def upload(self):
         check(self._L.hnsw_upload(self._h))
 

@@ -184,6 +184,12 @@ int hnsw_set_device(hnsw_index *h, int device);
 /* make the HBM snapshot current now (otherwise done lazily by the first search after a mutation) */
 int hnsw_upload(hnsw_index *h);
 int hnsw_device_bytes(const hnsw_index *h, uint64_t *bytes);
+/* tuning knobs of the HBM snapshot (take effect at the next upload):
+ *   "inline_rows"      -1 auto (default) / 0 never / 1 always: the layer-0 "inline rows" layout (a
+ *                      copy of every neighbour's vector row next to the adjacency slot, so that one
+ *                      expansion is one coalesced read; costs 2m x the row bytes of HBM)
+ *   "inline_budget_mb" largest inline-rows allocation the auto mode accepts (default 65536) */
+int hnsw_set_option(hnsw_index *h, const char *key, int64_t value);
 
 /* ---- harness helpers (not part of the reference's API) --------------------------------------- */
 /* Synthetic "GloVe-shaped" data, counter-based so any row can be generated independently:

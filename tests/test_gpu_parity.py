@@ -129,8 +129,11 @@ def test_rows_longer_than_the_adjacency_stride():
     orc2.set_ep(orc.ep)
     index = product_from_oracle(orc2, vs, lv)
     assert index.get_layer(0).degree(5) > 64
-    for ef in (1, 10, 64):
-        assert_search_equal(index.search_batch(qs, 10, ef), orc2.search_batch(qs, 10, ef), "overflow ef=%d" % ef)
+    for inline_rows in (1, 0):
+        index.set_option("inline_rows", inline_rows)
+        for ef in (1, 10, 64):
+            assert_search_equal(index.search_batch(qs, 10, ef), orc2.search_batch(qs, 10, ef),
+                                "overflow ef=%d inline=%d" % (ef, inline_rows))
 
 
 def test_duplicate_and_constant_vectors():
@@ -187,10 +190,26 @@ def synth20k():
     return index, orc, qs
 
 
+@pytest.mark.parametrize("inline_rows", [1, 0])
 @pytest.mark.parametrize("ef", [16, 64, 96, 256])
-def test_synthetic_glove_shaped_100d(synth20k, ef):
+def test_synthetic_glove_shaped_100d(synth20k, ef, inline_rows):
+    """both HBM layouts of layer 0: inline rows (one coalesced block per expansion, next block
+    prefetched) and compact rows + adjacency gather"""
     index, orc, qs = synth20k
-    assert_search_equal(index.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=8), "ef=%d" % ef)
+    index.set_option("inline_rows", inline_rows)
+    assert_search_equal(index.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=8),
+                        "ef=%d inline=%d" % (ef, inline_rows))
+    index.set_option("inline_rows", -1)
+
+
+@pytest.mark.parametrize("inline_rows", [1, 0])
+def test_layouts_on_reference_test_data(glove, inline_rows):
+    index, orc, queries = glove
+    index.set_option("inline_rows", inline_rows)
+    for ef in (1, 10, 100):
+        assert_search_equal(index.search_batch(queries, 10, ef), orc.search_batch(queries, 10, ef),
+                            "ef=%d inline=%d" % (ef, inline_rows))
+    index.set_option("inline_rows", -1)
 
 
 def test_true_recall_of_the_synthetic_set(synth20k):
