@@ -65,7 +65,7 @@ def main():
     import torch.distributed as dist
 
     import hnsw_rs_amd as H
-    from hnsw_rs_amd.distributed import ShardedSearcher, make_device_search
+    from hnsw_rs_amd.distributed import PipelinedShardedSearch, ShardedSearcher, make_device_search
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -76,8 +76,14 @@ def main():
         sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    # HNSW_BENCH_FORCE_DIST=1 runs the scatter / gather path even with one rank (a smoke test of the
+    # multi-GPU code on a single-GPU box)
+    force_dist = os.environ.get("HNSW_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ["MASTER_PORT"] = os.environ.get("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     kind = H.VEC_QUANT8 if args.kind == "quant8" else H.VEC_F32
     N, d, m, n, B = args.n_points, args.dim, args.m, args.topn, args.batch
@@ -159,19 +165,41 @@ def main():
 
     # ---- device buffers -------------------------------------------------------------------------
     local_search = make_device_search(index, n, ef, B, dev)
-    searcher = ShardedSearcher(local_search, d, n, dev)
+    searcher = ShardedSearcher(local_search, d, n, dev, force_collectives=force_dist)
     if rank == 0:
         dQ = torch.from_numpy(queries).to(dev).view(nqb, B * world, d)
     else:
         dQ = None
     torch.cuda.synchronize()
 
-    def step(i):
-        q = dQ[i % nqb] if rank == 0 else None
-        return searcher.search(q, B * world)
+    use_dist = world > 1 or force_dist
+    G = 8  # steps per exchange group (bucketed collectives)
+    pipe = PipelinedShardedSearch(index, d, n, ef, B, dev, group_steps=G) if use_dist else None
 
-    for i in range(args.warmup):
-        step(i)
+    def run_steps(first, count):
+        """`count` steps starting at step index `first`"""
+        if pipe is None:
+            for i in range(first, first + count):
+                searcher.search(dQ[i % nqb], B * world)
+            return
+        i = first
+        while i < first + count:
+            g = min(G, first + count - i)
+            qg = None
+            if rank == 0:
+                qg = torch.stack([dQ[(i + j) % nqb] for j in range(g)], 0)
+            pipe.submit(qg, g)  # scatter / searches / gather of neighbouring groups overlap
+            i += g
+
+    run_steps(0, args.warmup)
+    if pipe is not None:
+        pipe.finish()
+        if rank == 0 and args.warmup > 0:  # the exchange returns what a local search returns
+            last = args.warmup - 1
+            chk_ids, chk_d = pipe.results(pipe.n_groups - 1, last % G)
+            ref_ids, ref_d = local_search(dQ[last % nqb][:B].contiguous())
+            torch.cuda.synchronize()
+            assert torch.equal(chk_ids[:B], ref_ids) and torch.equal(chk_d[:B], ref_d), "gathered != local"
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -181,13 +209,14 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    for i in range(K):
-        if world == 1:
+    if pipe is None:
+        for i in range(K):
             ev[i][0].record()
-            step(args.warmup + i)
+            searcher.search(dQ[(args.warmup + i) % nqb], B * world)
             ev[i][1].record()
-        else:
-            step(args.warmup + i)
+    else:
+        run_steps(args.warmup, K)
+        pipe.finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -201,7 +230,7 @@ def main():
     # ---- per-launch kernel time (HIP events on the launch stream) and algorithmic bytes -----------
     result = {}
     if rank == 0:
-        if world == 1:
+        if pipe is None:
             kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         else:
             # time the search launch alone on this rank's slice
@@ -326,7 +355,7 @@ def main():
         }
         out.update(result)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 
