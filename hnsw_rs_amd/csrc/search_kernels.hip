@@ -34,6 +34,8 @@
 // `acc += t * t`; sqrt and the quantiser's division are the correctly rounded forms hipcc emits
 // by default.  Accumulation order is the reference's (quant.rs:23-36, full.rs:24-28).
 
+#include <cstdlib>
+
 #include "device_index.h"
 
 namespace hx {
@@ -68,6 +70,26 @@ __device__ __forceinline__ float pair_swap(float x) {
 }
 __device__ __forceinline__ int pair_swap_i(int x) {
     return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);
+}
+// Orders this wave's LDS traffic (one wave's DS operations execute in issue order; the clobber keeps
+// the compiler from moving accesses across).  The per-query state of a wave is private to it, so no
+// workgroup barrier is needed -- and none may be used where only some waves of a workgroup run.
+__device__ __forceinline__ void wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// workgroup barrier that does not drain VMEM (LDS-DMA prefetches stay in flight across it)
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// value held by lane q (0..3) of this lane's quad
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x),
+                                                                  Q * 0x55, 0xF, 0xF, true));
+}
+template <int Q>
+__device__ __forceinline__ int quad_bcast_i(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, Q * 0x55, 0xF, 0xF, true);
 }
 // Rust `f32 as u8`: saturating, NaN -> 0
 __device__ __forceinline__ uint32_t f32_as_u8(float x) {
@@ -126,6 +148,71 @@ __device__ __forceinline__ void quant_half_sums(const uint4 (&w)[P], const QSrc 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Four lanes per candidate (two-wave kernel): lane (h, sub) of the quad owns running sums
+// 4h + 2 sub and 4h + 2 sub + 1 of distance_unrolled, i.e. bytes 2 sub and 2 sub + 1 of every chunk
+// dword of half h; the d % 8 tail belongs to lane (0, 0) alone.  qc[2 c + kk] is this lane's query
+// value for chunk dword c, byte kk; qt[r] the tail values (lane (0,0) only).
+// ---------------------------------------------------------------------------------------------
+template <int P, int DS, typename QC, typename QT>
+__device__ __forceinline__ void quant_pair_sums(const uint4 (&w)[P], const QC &qc, const QT &qt,
+                                                int h, int sub, uint32_t nch4, uint32_t rem,
+                                                float (&acc)[2]) {
+    const float mn = __builtin_bit_cast(float, w[0].x);
+    const float delta = __builtin_bit_cast(float, w[0].y);
+    const bool tail_lane = (h == 0) && (sub == 0);
+    const uint32_t sh = 16u * (uint32_t)sub;
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const uint32_t dw[4] = {w[p].x, w[p].y, w[p].z, w[p].w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (p == 0 && j < 2) continue;  // header
+            const int e0 = 16 * p + 4 * j - 8;  // element index of byte 0 of this dword
+            const int c = e0 / 4;               // chunk dword number
+            bool is_chunk, is_tail;
+            if (DS > 0) {
+                constexpr int N4 = 4 * (DS / 8), RM = DS % 8;
+                is_chunk = e0 < N4;
+                is_tail = !is_chunk && e0 < N4 + RM;
+                if (!is_chunk && !is_tail) continue;
+            } else {
+                is_chunk = (uint32_t)e0 < nch4;
+                is_tail = !is_chunk && (uint32_t)e0 < nch4 + rem;
+            }
+            if (DS > 0 ? is_chunk : true) {
+                const uint32_t u = dw[j] >> sh;
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++) {
+                    const float x = ((float)((u >> (8 * kk)) & 0xFFu) * delta) + mn;
+                    const float t = x - qc[2 * c + kk];
+                    const float t2 = t * t;
+                    acc[kk] += (DS > 0 || is_chunk) ? t2 : 0.0f;
+                }
+            }
+            if (DS > 0 ? is_tail : true) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int e = e0 + k;
+                    bool in;
+                    if (DS > 0) {
+                        constexpr int N4 = 4 * (DS / 8), RM = DS % 8;
+                        if (e >= N4 + RM) continue;
+                        in = true;
+                    } else {
+                        in = is_tail && (uint32_t)e < nch4 + rem;
+                    }
+                    const float x = ((float)((dw[j] >> (8 * k)) & 0xFFu) * delta) + mn;
+                    const int r = DS > 0 ? e - 4 * (DS / 8) : (in ? e - (int)nch4 : 0);
+                    const float t = x - qt[r];
+                    const float t2 = t * t;
+                    acc[0] += (in && tail_lane) ? t2 : 0.0f;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stage one query in LDS.  QUANT8: the query is quantised with its own min / delta exactly like
 // a stored vector (Point::new -> QuantVec::new, template.rs:313, quant.rs:41-66) and kept
 // dequantised, y = code * delta + min, split into the two half-row element orders:
@@ -151,7 +238,7 @@ __device__ __forceinline__ bool stage_query(const DevView &v, const float *qv, f
         }
         const float delta = (hi - lo) / 255.0f;  // (ub - lb) / (2^8 - 1)
         for (uint32_t e = lane; e < 2 * nq_half; e += 64) yq[e] = 0.0f;
-        __syncthreads();
+        wave_fence();
         const uint32_t full = d & ~7u;
         for (uint32_t e = lane; e < d; e += 64) {
             float b = (qv[e] - lo) / delta;
@@ -174,7 +261,7 @@ __device__ __forceinline__ bool stage_query(const DevView &v, const float *qv, f
             yq[e] = x;
         }
     }
-    __syncthreads();
+    wave_fence();
     return __ballot(bad) == 0;
 }
 
@@ -291,6 +378,22 @@ __device__ __forceinline__ void dma_piece_to_lds(const void *gsrc, uint32_t lds_
         : "memory");
 }
 
+// Loads that the compiler's s_waitcnt bookkeeping does not see, each with its own wait.  They serve
+// the rare degree > 32 rows inside the inline-rows loops: a single compiler-visible VMEM load
+// anywhere in that loop nest makes hipcc drain vmcnt(0) at the loop header on EVERY iteration,
+// which would serialise the block prefetch (measured: the prefetch then gains nothing).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t asm_ld32(const void *p) {
+    uint32_t r;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ uint4 asm_ld128(const void *p) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p) : "memory");
+    return make_uint4(r.x, r.y, r.z, r.w);
+}
+
 // LDS-resident query values of one half
 struct QLds {
     const float *p;
@@ -385,13 +488,13 @@ struct WaveList {
         }
         if (surv && my_rank < ef) perm[my_rank] = key;
         n_cur = min(n_cur + m, ef);
-        __syncthreads();  // single-wave workgroup: orders the LDS writes before the reads
+        wave_fence();  // single-wave workgroup: orders the LDS writes before the reads
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t idx = 64u * r + lane;
             L[r] = idx < n_cur ? perm[idx] : KEY_INVALID;
         }
-        __syncthreads();
+        wave_fence();
         refresh_last(ef);
     }
 
@@ -504,7 +607,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
     wl.last_key = KEY_INVALID;
 
     // ---- distance of one candidate per lane group; returns the key on the group's first lane
-    auto eval_key = [&](uint32_t id, bool active) -> u64 {
+    auto eval_key = [&](uint32_t id, bool active, bool hidden_loads) -> u64 {
         float dist = 0.0f;
         if (KIND == HNSW_VEC_QUANT8 && P > 0) {
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -512,8 +615,13 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                 const uint4 *src = reinterpret_cast<const uint4 *>(
                     v.rows + (size_t)id * v.row_stride + (size_t)h * v.half_bytes);
                 uint4 w[P > 0 ? P : 1];
+                if (FAT && hidden_loads) {
 #pragma unroll
-                for (int p = 0; p < P; p++) w[p] = src[p];
+                    for (int p = 0; p < P; p++) w[p] = asm_ld128(src + p);
+                } else {
+#pragma unroll
+                    for (int p = 0; p < P; p++) w[p] = src[p];
+                }
                 if (DS > 0)
                     quant_half_sums<(P > 0 ? P : 1), DS>(w, qreg, h, v.nch4, v.rem, acc);
                 else
@@ -545,7 +653,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
     };
 
     // ---- one pass over up to CHUNK neighbour ids (one per lane group) ----
-    auto process = [&](uint32_t id, bool valid, bool visit, uint32_t ef_l) {
+    auto process = [&](uint32_t id, bool valid, bool visit, uint32_t ef_l, bool hidden_loads = false) {
         bool fresh = valid;
         if (visit) {
             bool f = false;
@@ -556,7 +664,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
         const u64 fm = __ballot(fresh && h == 0);
         if (fm == 0) return;
         n_dist += (uint32_t)__popcll(fm);
-        u64 key = eval_key(id, fresh);
+        u64 key = eval_key(id, fresh, hidden_loads);
         if (__ballot(status != HNSW_OK)) status = HNSW_ERR_NAN_INPUT;
         wl.merge(key, ef_l, perm, lane);
     };
@@ -587,7 +695,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
         for (uint32_t s = lane; s < (hslots >> 2); s += 64)
             reinterpret_cast<uint4 *>(htab)[s] =
                 make_uint4(HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT);
-        __syncthreads();
+        wave_fence();
         n_vis = 0;
         // candidates ∪= selected, visited ∪= ids(selected)  (searcher.rs:32-33)
 #pragma unroll
@@ -615,10 +723,20 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
             bool have_spec = false;
             uint32_t spec_id = 0, spec_sel = 0;
             const size_t lane_off = (size_t)cslot * v.row_stride + (size_t)h * v.half_bytes;
+            // The hot loop below holds no compiler-visible VMEM load: hipcc drains vmcnt(0) at the
+            // header of any loop with such a load somewhere inside, which would also drain the
+            // prefetch.  The rare degree > 32 rows leave the hot loop, are served from the compact
+            // layout with plain loads, and re-enter it.
+            uint32_t ovf_pending = HX_EMPTY_SLOT;
+            bool done = false;
+            while (!done && status == HNSW_OK) {
             while (true) {
                 STAMP(t0);
                 const int cpos = wl.first_unexpanded(lane);
-                if (cpos < 0) break;
+                if (cpos < 0) {
+                    done = true;
+                    break;
+                }
                 uint32_t cid = 0;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
@@ -740,12 +858,24 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                         STAMP_ADD(3, t3, t4);
                     }
                 }
-                if (ovf != HX_EMPTY_SLOT) {  // degree > S0: the rest of the row, compact rows
-                    const uint32_t lo = v.ovf_off[ovf], hi = v.ovf_off[ovf + 1];
+                if (ovf != HX_EMPTY_SLOT) {
+                    ovf_pending = ovf;
+                    break;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no prefetch in flight outside the hot loop
+            have_spec = false;
+            if (done || status != HNSW_OK) break;
+            {  // degree > S0: the rest of the row, from the compact rows
+                const uint32_t ovf = ovf_pending;
+                ovf_pending = HX_EMPTY_SLOT;
+                {
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)asm_ld32(v.ovf_off + ovf));
+                    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)asm_ld32(v.ovf_off + ovf + 1));
                     for (uint32_t base = lo; base < hi; base += CHUNK) {
                         const uint32_t i = base + cslot;
                         const bool ov = i < hi;
-                        const uint32_t onb = ov ? v.ovf_nbrs[i] : HX_EMPTY_SLOT;
+                        const uint32_t onb = ov ? asm_ld32(v.ovf_nbrs + i) : HX_EMPTY_SLOT;
                         const uint32_t ocnt = (uint32_t)__popcll(__ballot(ov && h == 0));
                         sum_deg += ocnt;
                         if (n_vis + ocnt > vis_limit) {
@@ -753,12 +883,11 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                             break;
                         }
                         n_vis += ocnt;
-                        process(onb, ov, true, ef_l);
+                        process(onb, ov, true, ef_l, true);
                         if (status != HNSW_OK) break;
                     }
-                    have_spec = false;  // the list may have changed after the prediction was made
-                    if (status != HNSW_OK) break;
                 }
+            }
             }
             continue;
         }
@@ -863,6 +992,538 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
     }
 }
 
+// =============================================================================================
+// Two-wave search kernel (QUANT8, inline-rows layout, m <= 16): ONE QUERY PER 128-THREAD
+// WORKGROUP.  A batch of 1024 queries is only one wave per SIMD for the one-wave kernel, and a
+// lone wave issues at most one vector instruction every four cycles; giving every query two
+// waves doubles the waves per SIMD and halves each wave's share of an expansion:
+//   - wave w owns adjacency slots 16w .. 16w+15, FOUR lanes per slot (lane (h, sub) of the quad:
+//     running sums 4h + 2 sub, 4h + 2 sub + 1 of distance_unrolled), DMA-stages only its half of
+//     the 4-KiB block, filters its 16 ids through the SHARED visited table;
+//   - both waves keep an identical copy of the sorted list in registers: after the distance step
+//     they exchange their <= 16 keys through LDS (one workgroup barrier per expansion) and each
+//     merges all 32, so pick / predict / merge never need another word of communication.
+// Wave 0 alone walks the entry point and the upper layers (ef = 1) on the compact layout, then
+// hands its list to wave 1.  Results are those of the one-wave kernel bit for bit (the batch a
+// merge sees is the same set of keys, and merging is order-independent).
+// =============================================================================================
+template <int N>
+struct QRegs2 {
+    float v[N];
+    __device__ __forceinline__ float operator[](int i) const { return v[i]; }
+};
+struct QcLds {  // chunk values of one (h, sub) lane: element 4 (i / 2) + 2 sub + i % 2 of the half
+    const float *p;
+    __device__ __forceinline__ float operator[](int i) const { return p[4 * (i >> 1) + (i & 1)]; }
+};
+
+template <int P, int DS, int R>
+__global__ void __launch_bounds__(128)
+hx_search2_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KIND = HNSW_VEC_QUANT8;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t q = a.qsel ? a.qsel[blockIdx.x] : blockIdx.x;
+    const uint32_t hslots = 1u << slots_log2, hmask = hslots - 1;
+    const uint32_t vis_limit = hslots - (hslots >> 2);
+    const uint32_t yq_bytes = ((2u * (v.half_bytes - 8) * 4u) + 15u) & ~15u;
+    constexpr uint32_t HALF_BLK = 16u * 32u * P;  // bytes of one wave's half block (16 rows)
+    // LDS carve (all dynamic): visited table | per-wave perm | exchange | per-wave yq | per-wave images
+    uint32_t off = 0;
+    uint32_t *htab = reinterpret_cast<uint32_t *>(smem);
+    off += 4u * hslots;
+    u64 *perm = reinterpret_cast<u64 *>(smem + off) + 64 * R * wv;
+    u64 *perm0 = reinterpret_cast<u64 *>(smem + off);
+    off += 2u * 64u * R * 8u;
+    u64 *xkeys = reinterpret_cast<u64 *>(smem + off);  // [2 parities][32 slots]
+    off += 2u * 32u * 8u;
+    uint32_t *xmeta = reinterpret_cast<uint32_t *>(smem + off);  // [2 parities][2 waves][4]
+    off += 2u * 2u * 4u * 4u;
+    float *yq = reinterpret_cast<float *>(smem + off + yq_bytes * wv);
+    off += 2u * yq_bytes;
+    unsigned char *img = smem + off + 2u * HALF_BLK * wv;  // this wave's two half-block images
+    const uint32_t img_lds = __builtin_amdgcn_groupstaticsize() + off + 2u * HALF_BLK * wv;
+
+    const uint32_t d = v.dim;
+    const float *qv = a.Q + (size_t)q * d;
+    uint32_t n_dist = 0, n_exp = 0, sum_deg = 0, n_vis = 0;
+    int32_t status = HNSW_OK;
+#ifdef HX_STAMPS
+    unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
+
+    // every wave stages its own copy of the query
+    const uint32_t nq_half = v.half_bytes - 8;
+    if (!stage_query<KIND>(v, qv, yq, lane)) status = HNSW_ERR_NAN_INPUT;
+
+    WaveList<R> wl;
+#pragma unroll
+    for (int r = 0; r < R; r++) wl.L[r] = KEY_INVALID;
+    wl.n_cur = 0;
+    wl.last_key = KEY_INVALID;
+
+    // ------------------------------------------------------------------------------------------
+    // wave 0: entry point + upper layers (ef = 1), two lanes per candidate on the compact layout
+    // ------------------------------------------------------------------------------------------
+    if (wv == 0 && status == HNSW_OK) {
+        const int h2 = lane & 1, cslot2 = lane >> 1;
+        constexpr int NQR = DS > 0 ? (4 * (DS / 8) + DS % 8) : 1;
+        QRegs<NQR> qreg;
+        if (DS > 0) {
+#pragma unroll
+            for (int e = 0; e < NQR; e++) qreg.v[e] = yq[h2 * nq_half + e];
+        }
+        const QLds qlds{yq + h2 * nq_half};
+        auto eval2 = [&](uint32_t id, bool active) -> u64 {
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (active) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(
+                    v.rows + (size_t)id * v.row_stride + (size_t)h2 * v.half_bytes);
+                uint4 w[P];
+#pragma unroll
+                for (int p = 0; p < P; p++) w[p] = src[p];
+                if (DS > 0)
+                    quant_half_sums<P, DS>(w, qreg, h2, v.nch4, v.rem, acc);
+                else
+                    quant_half_sums<P, 0>(w, qlds, h2, v.nch4, v.rem, acc);
+            }
+            const float b0 = pair_swap(acc[0]), b1 = pair_swap(acc[1]), b2 = pair_swap(acc[2]),
+                        b3 = pair_swap(acc[3]);
+            float s = 0.0f;
+            s += acc[0];
+            s += acc[1];
+            s += acc[2];
+            s += acc[3];
+            s += b0;
+            s += b1;
+            s += b2;
+            s += b3;
+            const float dist = __builtin_sqrtf(s);
+            if (!(active && h2 == 0)) return KEY_INVALID;
+            if (dist != dist) {
+                status = HNSW_ERR_NAN_INPUT;
+                return KEY_INVALID;
+            }
+            return ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | id;
+        };
+        auto process2 = [&](uint32_t id, bool valid, bool visit) {
+            bool fresh = valid;
+            if (visit) {
+                bool f = false;
+                if (valid && h2 == 0) f = visited_insert(htab, hmask, slots_log2, id);
+                fresh = (pair_swap_i(f ? 1 : 0) | (f ? 1 : 0)) != 0;
+            }
+            const u64 fm = __ballot(fresh && h2 == 0);
+            if (fm == 0) return;
+            n_dist += (uint32_t)__popcll(fm);
+            u64 key = eval2(id, fresh);
+            if (__ballot(status != HNSW_OK)) status = HNSW_ERR_NAN_INPUT;
+            wl.merge(key, 1u, perm, lane);
+        };
+        // entry: {ep} (template.rs:316-319)
+        process2(v.ep, lane < 2, false);
+        for (int layer = (int)v.nb_layers - 1; status == HNSW_OK && layer >= 1; layer--) {
+            for (uint32_t s = lane; s < (hslots >> 2); s += 64)
+                reinterpret_cast<uint4 *>(htab)[s] =
+                    make_uint4(HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT);
+            wave_fence();
+            if (lane == 0 && wl.n_cur > 0) {
+                wl.L[0] &= KEY_MASK;
+                visited_insert(htab, hmask, slots_log2, (uint32_t)wl.L[0]);
+            }
+            n_vis = wl.n_cur;
+            wl.refresh_last(1u);
+            const uint32_t S = v.S1;
+            while (true) {
+                const int cpos = wl.first_unexpanded(lane);
+                if (cpos < 0) break;
+                const uint32_t cid = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wl.L[0], 0);
+                if (lane == 0) wl.L[0] |= KEY_EXPANDED;
+                n_exp++;
+                const uint32_t ub = v.upper_base[cid];
+                if (ub == HX_EMPTY_SLOT) {
+                    status = HNSW_ERR_NODE_NOT_IN_GRAPH;
+                    break;
+                }
+                const uint32_t *row = v.adj_up + ((size_t)ub + layer - 1) * S;
+                uint32_t ovf = HX_EMPTY_SLOT;
+                for (uint32_t c0 = 0; c0 < S; c0 += 32) {
+                    const uint32_t slot = c0 + cslot2;
+                    uint32_t nb = HX_EMPTY_SLOT;
+                    if (slot < S) nb = row[slot];
+                    const bool is_ptr = nb != HX_EMPTY_SLOT && (nb & HX_OVF_FLAG);
+                    const bool valid = nb != HX_EMPTY_SLOT && !is_ptr;
+                    const u64 pm = __ballot(is_ptr);
+                    if (pm) ovf = (uint32_t)__builtin_amdgcn_readlane((int)nb, __ffsll((long long)pm) - 1) & ~HX_OVF_FLAG;
+                    const uint32_t cnt = (uint32_t)__popcll(__ballot(valid && h2 == 0));
+                    if (cnt == 0) continue;
+                    sum_deg += cnt;
+                    if (n_vis + cnt > vis_limit) {
+                        status = HNSW_ERR_OVERFLOW;
+                        break;
+                    }
+                    n_vis += cnt;
+                    process2(nb, valid, true);
+                    if (status != HNSW_OK) break;
+                }
+                if (status == HNSW_OK && ovf != HX_EMPTY_SLOT) {
+                    const uint32_t lo = v.ovf_off[ovf], hi = v.ovf_off[ovf + 1];
+                    for (uint32_t base = lo; base < hi; base += 32) {
+                        const uint32_t i = base + cslot2;
+                        const bool valid = i < hi;
+                        const uint32_t nb = valid ? v.ovf_nbrs[i] : HX_EMPTY_SLOT;
+                        const uint32_t cnt = (uint32_t)__popcll(__ballot(valid && h2 == 0));
+                        sum_deg += cnt;
+                        if (n_vis + cnt > vis_limit) {
+                            status = HNSW_ERR_OVERFLOW;
+                            break;
+                        }
+                        n_vis += cnt;
+                        process2(nb, valid, true);
+                        if (status != HNSW_OK) break;
+                    }
+                }
+                if (status != HNSW_OK) break;
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // hand-over: wave 0 publishes (status, n_cur, list); both clear the visited table
+    // ------------------------------------------------------------------------------------------
+    wg_barrier();  // wave 1 must not touch the visited table while wave 0 walks the upper layers
+    if (wv == 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++) perm0[64 * r + lane] = wl.L[r] & KEY_MASK;  // candidates ∪= selected
+        if (lane == 0) {
+            xmeta[0] = (uint32_t)status;
+            xmeta[1] = wl.n_cur;
+        }
+    }
+    for (uint32_t s = threadIdx.x; s < (hslots >> 2); s += 128)
+        reinterpret_cast<uint4 *>(htab)[s] =
+            make_uint4(HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT);
+    wg_barrier();
+    {
+        status = (int32_t)xmeta[0];  // wave 0's verdict is the workgroup's
+        wl.n_cur = xmeta[1];
+#pragma unroll
+        for (int r = 0; r < R; r++) wl.L[r] = perm0[64 * r + lane];
+    }
+    const uint32_t ef = max(1u, a.ef_bottom);
+    if (wv == 0) {  // visited ∪= ids(selected)  (searcher.rs:33)
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (64u * r + lane < wl.n_cur) visited_insert(htab, hmask, slots_log2, (uint32_t)wl.L[r]);
+    }
+    n_vis = wl.n_cur;
+    wl.refresh_last(ef);
+    wg_barrier();  // also: xmeta / perm0 free for reuse
+
+    // ------------------------------------------------------------------------------------------
+    // layer 0: both waves, four lanes per slot, inline-rows blocks staged by LDS-DMA
+    // ------------------------------------------------------------------------------------------
+    if (status == HNSW_OK) {
+        const int g = lane >> 2, j4 = lane & 3, h = j4 >> 1, sub = j4 & 1;
+        const bool leader = j4 == 0;
+        constexpr int NCD = DS > 0 ? (DS / 8) : 1;    // chunk dwords per half
+        constexpr int NTL = DS > 0 ? (DS % 8) : 1;    // tail elements
+        QRegs2<2 * NCD> qc;
+        QRegs2<(NTL > 0 ? NTL : 1)> qt;
+        if (DS > 0) {
+#pragma unroll
+            for (int i = 0; i < 2 * NCD; i++) qc.v[i] = yq[h * nq_half + 4 * (i >> 1) + 2 * sub + (i & 1)];
+#pragma unroll
+            for (int r = 0; r < NTL; r++) qt.v[r] = yq[v.nch4 + r];
+        }
+        const QcLds qc_lds{yq + h * nq_half + 2 * sub};
+        const QLds qt_lds{yq + v.nch4};
+        uint4 w[P];
+        bool have_spec = false;
+        uint32_t spec_id = 0, spec_sel = 0, par = 0;
+        // DMA source of this lane within a block: this wave's 16 rows, 1-KiB pieces
+        const size_t dma_off = (size_t)wv * HALF_BLK + (size_t)lane * 16;
+        // where lane (g, h) reads its half row in an image
+        const uint32_t rd_off = (uint32_t)g * v.row_stride + (uint32_t)h * v.half_bytes;
+        constexpr int NPIECE = HALF_BLK / 1024;
+        // (the hot loop holds no compiler-visible VMEM load, see the one-wave kernel)
+        uint32_t ovf_pending = HX_EMPTY_SLOT;
+        bool done = false;
+        while (!done && status == HNSW_OK) {
+        while (true) {
+            STAMP(t0);
+            const int cpos = wl.first_unexpanded(lane);
+            if (cpos < 0) {
+                done = true;
+                break;
+            }
+            uint32_t cid = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if ((cpos >> 6) == r) {
+                    cid = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wl.L[r], cpos & 63);
+                    if (lane == (cpos & 63)) wl.L[r] |= KEY_EXPANDED;
+                }
+            }
+            n_exp++;
+            const bool hit = have_spec && spec_id == cid;
+#ifdef HX_STAMPS
+            if (hit) dbg_acc[6]++;
+#endif
+            uint32_t cur_sel = spec_sel;
+            if (!hit) {
+                cur_sel = spec_sel ^ 1u;
+                const unsigned char *src = v.fat + (size_t)cid * v.fat_stride + dma_off;
+#pragma unroll
+                for (int p = 0; p < NPIECE; p++)
+                    dma_piece_to_lds(src + 1024 * p, img_lds + cur_sel * HALF_BLK + 1024u * p);
+            }
+            have_spec = false;
+            {
+                const int ppos = wl.first_unexpanded(lane);
+                if (ppos >= 0) {
+                    uint32_t pid = 0;
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+                        if ((ppos >> 6) == r)
+                            pid = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wl.L[r], ppos & 63);
+                    spec_sel = cur_sel ^ 1u;
+                    const unsigned char *src = v.fat + (size_t)pid * v.fat_stride + dma_off;
+#pragma unroll
+                    for (int p = 0; p < NPIECE; p++)
+                        dma_piece_to_lds(src + 1024 * p, img_lds + spec_sel * HALF_BLK + 1024u * p);
+                    spec_id = pid;
+                    have_spec = true;
+                }
+            }
+            if (have_spec)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            {
+                const uint4 *src = reinterpret_cast<const uint4 *>(img + cur_sel * HALF_BLK + rd_off);
+#pragma unroll
+                for (int p = 0; p < P; p++) w[p] = src[p];
+            }
+            STAMP(t1);
+            STAMP_ADD(0, t0, t1);
+            // neighbour id: last 4 bytes of half 0, held by lanes h == 0 of the quad
+            const uint32_t nb = (uint32_t)quad_bcast_i<0>((int)w[P - 1].w);
+            const bool is_ptr = nb != HX_EMPTY_SLOT && (nb & HX_OVF_FLAG);
+            const bool valid = nb != HX_EMPTY_SLOT && !is_ptr;
+            uint32_t ovf = HX_EMPTY_SLOT;
+            {
+                const u64 pm = __ballot(is_ptr && leader);
+                if (pm) ovf = (uint32_t)__builtin_amdgcn_readlane((int)nb, __ffsll((long long)pm) - 1) & ~HX_OVF_FLAG;
+            }
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(valid && leader));
+            sum_deg += cnt;
+            int32_t lstat = HNSW_OK;
+            if (n_vis + 32 > vis_limit) lstat = HNSW_ERR_OVERFLOW;  // both waves reach the same verdict
+            u64 key = KEY_INVALID;
+            if (lstat == HNSW_OK && cnt != 0) {
+                bool f = false;
+                if (valid && leader) f = visited_insert(htab, hmask, slots_log2, nb);
+                const bool fresh = quad_bcast_i<0>(f ? 1 : 0) != 0;
+                const u64 fm = __ballot(fresh && leader);
+                STAMP(t2);
+                STAMP_ADD(1, t1, t2);
+                if (fm != 0) {
+                    n_dist += (uint32_t)__popcll(fm);
+                    float acc[2] = {0.0f, 0.0f};
+                    if (fresh) {
+                        if (DS > 0)
+                            quant_pair_sums<P, DS>(w, qc, qt, h, sub, v.nch4, v.rem, acc);
+                        else
+                            quant_pair_sums<P, 0>(w, qc_lds, qt_lds, h, sub, v.nch4, v.rem, acc);
+                    }
+                    // a0 .. a7 in order: lane 0 holds a0 a1, lane 1 a2 a3, lane 2 a4 a5, lane 3 a6 a7
+                    float s = 0.0f;
+                    s += quad_bcast<0>(acc[0]);
+                    s += quad_bcast<0>(acc[1]);
+                    s += quad_bcast<1>(acc[0]);
+                    s += quad_bcast<1>(acc[1]);
+                    s += quad_bcast<2>(acc[0]);
+                    s += quad_bcast<2>(acc[1]);
+                    s += quad_bcast<3>(acc[0]);
+                    s += quad_bcast<3>(acc[1]);
+                    const float dist = __builtin_sqrtf(s);
+                    if (fresh && leader) {
+                        if (dist != dist)
+                            lstat = HNSW_ERR_NAN_INPUT;
+                        else
+                            key = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | nb;
+                    }
+                }
+            }
+            if (__ballot(lstat == HNSW_ERR_NAN_INPUT)) lstat = HNSW_ERR_NAN_INPUT;
+            STAMP(t3);
+            STAMP_ADD(2, t1, t3);
+            // ---- exchange: keys of my 16 slots, my counts / verdict / overflow pointer ----
+            u64 *xk = xkeys + 32 * par;
+            uint32_t *xm = xmeta + 8 * par;
+            if (leader) xk[16 * wv + g] = key;
+            if (lane == 0) {
+                xm[4 * wv + 0] = cnt;
+                xm[4 * wv + 1] = (uint32_t)lstat;
+                xm[4 * wv + 2] = ovf;
+            }
+            wg_barrier();
+            const uint32_t ow = 1u - (uint32_t)wv;
+            const u64 okey = (j4 == 1) ? xk[16 * ow + g] : KEY_INVALID;
+            const uint32_t ocnt = xm[4 * ow + 0];
+            const int32_t ostat = (int32_t)xm[4 * ow + 1];
+            const uint32_t oovf = xm[4 * ow + 2];
+            par ^= 1u;
+            if (lstat == HNSW_OK) lstat = ostat;
+            if (lstat != HNSW_OK) {
+                status = lstat;
+                break;
+            }
+            n_vis += cnt + ocnt;
+            STAMP(t4);
+            STAMP_ADD(3, t3, t4);
+            wl.merge(leader ? key : okey, ef, perm, lane);
+            STAMP(t5);
+            STAMP_ADD(5, t4, t5);
+            if (ovf == HX_EMPTY_SLOT) ovf = oovf;
+            if (ovf != HX_EMPTY_SLOT) {
+                ovf_pending = ovf;
+                break;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no prefetch in flight outside the hot loop
+        have_spec = false;
+        if (done || status != HNSW_OK) break;
+            {
+                // degree > 32: the rest of the row lives in the overflow CSR (compact rows).  Wave 0
+                // evaluates it, two lanes per neighbour, and publishes the keys; both waves merge.
+                const uint32_t ovf = ovf_pending;
+                ovf_pending = HX_EMPTY_SLOT;
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)asm_ld32(v.ovf_off + ovf));
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)asm_ld32(v.ovf_off + ovf + 1));
+                for (uint32_t base = lo; base < hi; base += 32) {
+                    u64 *xk2 = xkeys + 32 * par;
+                    uint32_t *xm2 = xmeta + 8 * par;
+                    if (wv == 0) {
+                        const int h2 = lane & 1;
+                        const uint32_t i = base + (lane >> 1);
+                        const bool ov = i < hi;
+                        const uint32_t onb = ov ? asm_ld32(v.ovf_nbrs + i) : HX_EMPTY_SLOT;
+                        const uint32_t c2 = (uint32_t)__popcll(__ballot(ov && h2 == 0));
+                        int32_t st2 = HNSW_OK;
+                        u64 k2 = KEY_INVALID;
+                        if (n_vis + c2 > vis_limit) {
+                            st2 = HNSW_ERR_OVERFLOW;
+                        } else {
+                            bool f = false;
+                            if (ov && h2 == 0) f = visited_insert(htab, hmask, slots_log2, onb);
+                            const bool fresh = (pair_swap_i(f ? 1 : 0) | (f ? 1 : 0)) != 0;
+                            n_dist += (uint32_t)__popcll(__ballot(fresh && h2 == 0));
+                            float acc4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                            if (fresh) {
+                                const uint4 *src = reinterpret_cast<const uint4 *>(
+                                    v.rows + (size_t)onb * v.row_stride + (size_t)h2 * v.half_bytes);
+                                uint4 w2[P];
+#pragma unroll
+                                for (int p = 0; p < P; p++) w2[p] = asm_ld128(src + p);
+                                const QLds ql{yq + h2 * nq_half};
+                                quant_half_sums<P, 0>(w2, ql, h2, v.nch4, v.rem, acc4);
+                            }
+                            const float c0 = pair_swap(acc4[0]), c1 = pair_swap(acc4[1]),
+                                        c2b = pair_swap(acc4[2]), c3 = pair_swap(acc4[3]);
+                            float sm = 0.0f;
+                            sm += acc4[0];
+                            sm += acc4[1];
+                            sm += acc4[2];
+                            sm += acc4[3];
+                            sm += c0;
+                            sm += c1;
+                            sm += c2b;
+                            sm += c3;
+                            const float dist = __builtin_sqrtf(sm);
+                            if (fresh && h2 == 0) {
+                                if (dist != dist)
+                                    st2 = HNSW_ERR_NAN_INPUT;
+                                else
+                                    k2 = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | onb;
+                            }
+                            if (__ballot(st2 != HNSW_OK)) st2 = HNSW_ERR_NAN_INPUT;
+                        }
+                        sum_deg += c2;
+                        if (h2 == 0) xk2[lane >> 1] = k2;
+                        if (lane == 0) {
+                            xm2[0] = c2;
+                            xm2[1] = (uint32_t)st2;
+                        }
+                    }
+                    wg_barrier();
+                    const u64 k3 = ((lane & 1) == 0) ? xk2[lane >> 1] : KEY_INVALID;
+                    const uint32_t c3 = xm2[0];
+                    const int32_t st3 = (int32_t)xm2[1];
+                    par ^= 1u;
+                    if (st3 != HNSW_OK) {
+                        status = st3;
+                        break;
+                    }
+                    n_vis += c3;
+                    wl.merge(k3, ef, perm, lane);
+                }
+            }
+        }
+    }
+    // drain any prefetch still in flight before the LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ------------------------------------------------------------------------------------------
+    // results: wave 1 hands its counters over, wave 0 writes (results.rs:59-61)
+    // ------------------------------------------------------------------------------------------
+    wg_barrier();
+    if (wv == 1 && lane == 0) {
+        xmeta[0] = n_dist;
+        xmeta[1] = sum_deg;
+    }
+    wg_barrier();
+#ifdef HX_STAMPS
+    if (wv == 0 && lane == 0 && a.dbg) {
+        dbg_acc[4] = __builtin_readcyclecounter() - t_begin;
+        for (int i = 0; i < 8; i++) a.dbg[(size_t)q * 8 + i] = dbg_acc[i];
+    }
+#endif
+    if (wv == 0) {
+        n_dist += xmeta[0];
+        sum_deg += xmeta[1];
+        const uint32_t count = status == HNSW_OK ? min(a.n, wl.n_cur) : 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t idx = 64u * r + lane;
+            if (idx < a.n) {
+                const bool have = idx < count;
+                a.out_ids[(size_t)q * a.n + idx] = have ? (uint32_t)wl.L[r] : HX_EMPTY_SLOT;
+                if (a.out_dists)
+                    a.out_dists[(size_t)q * a.n + idx] =
+                        have ? __builtin_bit_cast(float, (uint32_t)((wl.L[r] & KEY_MASK) >> 32))
+                             : __builtin_inff();
+            }
+        }
+        for (uint32_t idx = 64u * R + lane; idx < a.n; idx += 64) {
+            a.out_ids[(size_t)q * a.n + idx] = HX_EMPTY_SLOT;
+            if (a.out_dists) a.out_dists[(size_t)q * a.n + idx] = __builtin_inff();
+        }
+        if (lane == 0) {
+            if (a.out_counts) a.out_counts[q] = count;
+            hnsw_query_stats st;
+            st.n_dist = n_dist;
+            st.n_exp = n_exp;
+            st.sum_deg = sum_deg;
+            st.status = status;
+            a.out_stats[q] = st;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
@@ -904,11 +1565,61 @@ static int launch_one(const DevView &v, const SearchArgs &a, uint32_t nblocks, u
     return HNSW_OK;
 }
 
+template <int P, int DS, int R>
+static int launch_two(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint32_t slots_log2,
+                      hipStream_t stream) {
+    const size_t yq_bytes = ((2ull * (v.half_bytes - 8) * 4) + 15) & ~15ull;
+    const size_t lds = (4ull << slots_log2) + 2ull * 64 * R * 8 + 2 * 32 * 8 + 2 * 2 * 4 * 4 +
+                       2 * yq_bytes + 2ull * 2 * (16ull * 32 * P);
+    auto kern = hx_search2_kernel<P, DS, R>;
+    if (lds > 160 * 1024) return HNSW_ERR_ARG;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+            return HNSW_ERR_HIP;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(128), lds, stream, v, a, slots_log2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("two-wave search kernel launch: %s", hipGetErrorString(e));
+        return HNSW_ERR_HIP;
+    }
+    return HNSW_OK;
+}
+
+// The two-wave kernel is opt-in (HNSW_MI355X_WAVES=2): measured on MI355X at 1M x 100d, batch 1024
+// it takes 0.207 ms per batch against 0.185 ms for the one-wave kernel -- halving the distance work
+// per wave does not pay for the key exchange + barrier and the replicated merge, because the loop
+// is bound by instruction latency (about 750 instructions at ~5 cycles each per expansion), not by
+// issue bandwidth.  Kept because it is parity-tested and documents the design point.
+static bool want_two_waves(uint32_t) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char *e = getenv("HNSW_MI355X_WAVES");
+        forced = e ? atoi(e) : 0;
+    }
+    return forced == 2;
+}
+
 template <int KIND, int P, int DS>
 static int launch_r(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint32_t slots_log2,
                     hipStream_t stream, uint32_t ef_max) {
     // the inline-rows variant needs one pass to cover a whole layer-0 row
     constexpr bool CAN_FAT = (KIND == HNSW_VEC_QUANT8 && P > 0);
+    if constexpr (CAN_FAT) {
+        // 16 rows per wave must be whole 1-KiB DMA pieces: row_stride * 16 % 1024 == 0
+        if (v.fat != nullptr && v.S0 == 32 && a.layer_lo == 0 && a.entries == nullptr &&
+            a.layer_hi == (int32_t)v.nb_layers - 1 && a.ef_upper == 1 && (16u * v.row_stride) % 1024u == 0 &&
+            v.row_stride == 32u * P && want_two_waves(nblocks)) {
+            if (ef_max <= 64) return launch_two<P, DS, 1>(v, a, nblocks, slots_log2, stream);
+            if (ef_max <= 128) return launch_two<P, DS, 2>(v, a, nblocks, slots_log2, stream);
+            if (ef_max <= 256) return launch_two<P, DS, 4>(v, a, nblocks, slots_log2, stream);
+            if (ef_max <= 512) return launch_two<P, DS, 8>(v, a, nblocks, slots_log2, stream);
+        }
+    }
     if (CAN_FAT && v.fat != nullptr && v.S0 == 32 && a.layer_lo == 0) {
         if (ef_max <= 64) return launch_one<KIND, P, DS, 1, CAN_FAT>(v, a, nblocks, slots_log2, stream);
         if (ef_max <= 128) return launch_one<KIND, P, DS, 2, CAN_FAT>(v, a, nblocks, slots_log2, stream);

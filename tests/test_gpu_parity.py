@@ -212,6 +212,30 @@ def test_layouts_on_reference_test_data(glove, inline_rows):
     index.set_option("inline_rows", -1)
 
 
+def test_two_wave_kernel_is_parity_exact(synth20k):
+    """the opt-in two-waves-per-query kernel (HNSW_MI355X_WAVES=2), in a child process because the
+    choice is read once per process"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import hnsw_rs_amd as H\n"
+        "from oracle import oracle_py as O\n"
+        "from tests.util import oracle_from_product, assert_search_equal\n"
+        "n, d, m = 6000, 100, 16\n"
+        "vs = H.synth_rows(0, 0x5EED0001, 0, n, d); qs = H.synth_rows(0, 0x5EED0002, 0, 128, d)\n"
+        "lv = O.draw_levels(n, m, 7)\n"
+        "idx = H.HNSW.new(m, 32, d).insert_bulk(vs, 4, False, levels=lv)\n"
+        "orc = oracle_from_product(idx, vs, lv)\n"
+        "for ef in (1, 64, 100):\n"
+        "    assert_search_equal(idx.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=4), 'w2 ef=%%d' %% ef)\n"
+        "print('two-wave ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, HNSW_MI355X_WAVES="2")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "two-wave ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_true_recall_of_the_synthetic_set(synth20k):
     index, orc, qs = synth20k
     bf, _ = index.brute_force(qs[:64], 10)
