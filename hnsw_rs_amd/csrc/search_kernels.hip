@@ -394,6 +394,26 @@ __device__ __forceinline__ uint4 asm_ld128(const void *p) {
     return make_uint4(r.x, r.y, r.z, r.w);
 }
 
+// FullVec row against the staged query when the dimension is a compile-time constant: all P
+// 16-byte pieces of the row are loaded up front (P x 16 bytes in flight per lane), the sum is the
+// reference's single left-to-right chain (full.rs:24-28).
+template <int P, int DS>
+__device__ __forceinline__ float f32_row_sum(const uint4 (&w)[P], const float *yq) {
+    float s = 0.0f;
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const uint32_t dw[4] = {w[p].x, w[p].y, w[p].z, w[p].w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int e = 4 * p + j;
+            if (e >= DS) continue;
+            const float t = __builtin_bit_cast(float, dw[j]) - yq[e];
+            s += t * t;
+        }
+    }
+    return s;
+}
+
 // LDS-resident query values of one half
 struct QLds {
     const float *p;
@@ -640,6 +660,16 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
             s += b2;
             s += b3;
             dist = __builtin_sqrtf(s);
+        } else if (KIND == HNSW_VEC_F32 && P > 0 && DS > 0) {
+            float sm = 0.0f;
+            if (active) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(v.rows + (size_t)id * v.row_stride);
+                uint4 w[P > 0 ? P : 1];
+#pragma unroll
+                for (int p = 0; p < P; p++) w[p] = src[p];
+                sm = f32_row_sum<(P > 0 ? P : 1), (DS > 0 ? DS : 1)>(w, yq);
+            }
+            dist = __builtin_sqrtf(sm);
         } else {
             dist = dist_any_dim<KIND>(v, id, active, h, yq);
         }
@@ -1653,6 +1683,8 @@ int launch_search(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint3
             default: return launch_r<HNSW_VEC_QUANT8, 0, 0>(v, a, nblocks, slots_log2, stream, ef_max);
         }
     }
+    if (v.dim == 100 && v.row_stride == 400)
+        return launch_r<HNSW_VEC_F32, 25, 100>(v, a, nblocks, slots_log2, stream, ef_max);
     return launch_r<HNSW_VEC_F32, 0, 0>(v, a, nblocks, slots_log2, stream, ef_max);
 }
 

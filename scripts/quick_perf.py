@@ -5,12 +5,13 @@ import numpy as np
 import torch
 import hnsw_rs_amd as H
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+KIND = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 ef = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 d, m, nq = 100, 16, 1024
 thr = min(32, os.cpu_count())
 t = time.time(); vs = H.synth_rows(0, 0x5EED0001, 0, N, d, thr); qs = H.synth_rows(0, 0x5EED0002, 0, nq * 8, d, thr)
 print('gen %.1fs cpus=%d' % (time.time() - t, os.cpu_count()), flush=True)
-t = time.time(); idx = H.HNSW.new(m, 32, d).insert_bulk(vs, thr, False); print('build %.1fs layers=%d' % (time.time() - t, idx.nb_layers()), flush=True)
+t = time.time(); idx = H.HNSW.new(m, 32, d, KIND).insert_bulk(vs, thr, False); print('build %.1fs layers=%d' % (time.time() - t, idx.nb_layers()), flush=True)
 t = time.time(); idx.upload(); print('upload %.1fs bytes=%.1fMB' % (time.time() - t, idx.device_bytes() / 1e6), flush=True)
 dev = torch.device('cuda:0')
 dQ = torch.from_numpy(qs).to(dev)
