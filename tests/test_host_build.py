@@ -147,3 +147,22 @@ def test_search_without_a_gpu_fails_loudly(gpu_available):
     with pytest.raises(H.HnswError) as e:
         index.ann_by_vector(rand_vectors(1, DIM, 2)[0], 10, 100)
     assert e.value.code in (_lib.ERR_NO_DEVICE, _lib.ERR_HIP)
+
+
+def test_glove_text_loader_matches_the_binary_fixture(testdata, tmp_path):
+    """load_glove_array (hnsw/src/helpers/glove.rs:14-71) on a text rendering of the fixture rows;
+    '%.9g' round-trips every f32, and strtof is the correctly rounded parse Rust performs"""
+    from hnsw_rs_amd.eval import load_glove_array
+    store, _ = testdata
+    path = tmp_path / "store.txt"
+    with open(path, "w") as f:
+        for i, row in enumerate(store[:50]):
+            f.write("w%d " % i + " ".join("%.9g" % x for x in row) + "\n")
+    words, arr = load_glove_array(0, path)
+    assert words[:3] == ["w0", "w1", "w2"] and np.array_equal(arr, store[:50])
+    words, arr = load_glove_array(7, path)
+    assert arr.shape == (7, 50)
+    with open(path, "a") as f:
+        f.write("odd 1.0 2.0\n")
+    with pytest.raises(ValueError):
+        load_glove_array(0, path)
