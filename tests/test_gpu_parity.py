@@ -277,3 +277,37 @@ def test_device_pointer_entry_point(synth20k):
     assert np.array_equal(d_dists.cpu().numpy().view(np.uint32), w_d.view(np.uint32))
     st = d_stats.cpu().numpy()
     assert (st[:, 3] == 0).all() and np.array_equal(st[:, :3].astype(np.uint64), w_s)
+
+
+@pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
+@pytest.mark.parametrize("m", [24, 32, 48])
+def test_wide_adjacency_rows(kind, m):
+    """m > 16: layer-0 rows of 64 / 128 slots are walked in several passes"""
+    n, d = 2500, 20
+    vs, qs = rand_vectors(n, d, 300 + m), rand_vectors(48, d, 400 + m)
+    index, orc = both(vs, O.draw_levels(n, m, m), m, kind, threads=4)
+    assert max(index.get_layer(0).degree(i) for i in range(0, n, 7)) > 32
+    for ef in (1, 40, 130):
+        assert_search_equal(index.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=4),
+                            "m=%d kind=%d ef=%d" % (m, kind, ef))
+
+
+@pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
+def test_bert_sized_vectors(kind):
+    """d = 768 (BASELINE configs[2] dimension): the any-dimension distance path"""
+    n, d, m = 400, 768, 8
+    vs, qs = rand_vectors(n, d, 77), rand_vectors(16, d, 78)
+    index, orc = both(vs, O.draw_levels(n, m, 5), m, kind)
+    for ef in (1, 32):
+        assert_search_equal(index.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef), "d=768 ef=%d" % ef)
+    ids = np.arange(n, dtype=np.uint32)
+    got, want = index.distance_batch(qs[0], ids), orc.distance_batch(qs[0], ids)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_host_pointer_batch_api_matches_single_queries(glove):
+    """hnsw_search_batch (nq queries) == nq calls of hnsw_search (the reference's one-query API)"""
+    index, _, queries = glove
+    ids, _, counts, _ = index.search_batch(queries[:12], 7, 30)
+    for q, row, c in zip(queries[:12], ids, counts):
+        assert index.ann_by_vector(q, 7, 30) == [int(x) for x in row[:c]]
