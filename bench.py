@@ -62,6 +62,9 @@ def parse():
     p.add_argument("--recipe", type=int, default=0, help="0 = A (low intrinsic dim), 1 = B (isotropic)")
     p.add_argument("--query-batches", type=int, default=10, help="distinct batches cycled through")
     p.add_argument("--build-threads", type=int, default=0)
+    p.add_argument("--cpu-build", action="store_true",
+                   help="build the index with the host threads only (default: on-device build, "
+                        "hnsw_insert_bulk_device)")
     p.add_argument("--cpu-threads", type=int, default=0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--recall-queries", type=int, default=1024)
@@ -93,9 +96,15 @@ def get_index(c, kind_name):
         if index is None:
             store = H.synth_rows(a.recipe, 0x5EED0001, 0, a.n_points, a.dim, min(32, c.ncpu))
             t1 = time.time()
-            index = H.HNSW.new(a.m, a.ef_cons, a.dim, kind).insert_bulk(store, c.build_threads, False)
-            log("built the %s index with %d threads in %.1fs, %d layers" % (
-                kind_name, c.build_threads, time.time() - t1, index.nb_layers()))
+            index = H.HNSW.new(a.m, a.ef_cons, a.dim, kind)
+            if a.cpu_build:
+                index.insert_bulk(store, c.build_threads, False)
+            else:
+                index.set_device(c.local_rank)
+                index.insert_bulk_device(store, c.build_threads, False)
+            log("built the %s index (%s, %d host threads) in %.1fs, %d layers" % (
+                kind_name, "host build" if a.cpu_build else "on-device build", c.build_threads,
+                time.time() - t1, index.nb_layers()))
             del store
             try:
                 os.makedirs(a.index_cache, exist_ok=True)

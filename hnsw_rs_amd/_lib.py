@@ -57,6 +57,7 @@ SYMBOLS = {
     "hnsw_set_ep": (C.c_int, [vp, C.c_uint32]),
     "hnsw_insert_bulk": (C.c_int, [vp, f32p, C.c_uint64, C.c_uint32, C.c_int]),
     "hnsw_insert_bulk_levels": (C.c_int, [vp, f32p, C.c_uint64, C.c_uint32, C.c_int, u8p]),
+    "hnsw_insert_bulk_device": (C.c_int, [vp, f32p, C.c_uint64, C.c_uint32, C.c_int, u8p]),
     "hnsw_insert_vec": (C.c_int, [vp, f32p, u32p]),
     "hnsw_insert_vec_level": (C.c_int, [vp, f32p, C.c_int, u32p]),
     "hnsw_import_points": (C.c_int, [vp, f32p, C.c_uint64, u8p]),

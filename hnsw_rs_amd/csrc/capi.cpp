@@ -5,11 +5,15 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "device_index.h"
@@ -21,6 +25,7 @@ struct hnsw_index {
     std::unique_ptr<hx::HostIndex> host;
     hx::DeviceIndex dev;
     int device = -1;
+    bool gpu_build = false;  // option "gpu_build": insert_bulk runs the on-device build
     std::mutex mu;
 };
 
@@ -171,6 +176,237 @@ int search_host(hnsw_index *h, hx::SearchArgs a_host, const float *Q, uint64_t n
     return HNSW_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// On-device index build: batch-synchronous insert_bulk.
+//   per batch:  GPU  hx_insert_kernel -- one wave per point: entry point, greedy descent, and for
+//                    every layer of the point search_layer(ef_cons) + select_heuristic
+//                    (inserter.rs:40-126) against the graph as it stands in HBM
+//               host connect_point   -- the reference's make_connections / prune_connections /
+//                    make_pruned_connections (template.rs:196-251) on `nb_threads` threads with the
+//                    per-row locks of the CPU build
+//               GPU  hx_scatter_rows -- the adjacency rows that changed go back to HBM
+// The first points (and any point whose search reports an error) take the CPU path, batches grow
+// with the graph (a batch never exceeds 1/8 of the points already connected, at most 4096): points
+// of one batch do not see each other, like the racing threads of the reference's own multi-threaded
+// insert_bulk.  The result is a valid HNSW graph judged by recall, not by identity.
+// ---------------------------------------------------------------------------------------------
+int gpu_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads, int verbose,
+                    const uint8_t *levels) {
+    using hx::NodeID;
+    hx::HostIndex &host = *h->host;
+    if (nb_threads == 0) nb_threads = 1;
+    if (host.params.m > 32 || host.params.ef_cons > 512) {
+        set_error("on-device build supports m <= 32 and ef_construction <= 512");
+        return HNSW_ERR_ARG;
+    }
+    const uint64_t n_before = host.len();
+    std::vector<NodeID> ids;
+    int rc = host.store_points(rows, n, levels, &ids);
+    if (rc != HNSW_OK) return rc;
+    host.prepare_build();
+    // insertion order of the reference: layers top-down, ids ascending inside a level (template.rs:403-416)
+    std::vector<NodeID> order;
+    order.reserve(ids.size());
+    for (NodeID id : ids)
+        if (id != host.params.ep) order.push_back(id);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](NodeID x, NodeID y) { return host.levels[x] > host.levels[y]; });
+
+    // ---- seed on the CPU: the first points must be inserted one after the other ----
+    const uint64_t SEED = 2048;
+    size_t pos = 0;
+    if (n_before < SEED) {
+        const size_t take = std::min<size_t>(order.size(), SEED - n_before);
+        std::vector<NodeID> seed(order.begin(), order.begin() + take);
+        // sequential (one Inserter) so that the seed graph is the reference's single-thread graph
+        std::unique_ptr<hx::Inserter, void (*)(hx::Inserter *)> ins(hx::new_inserter(host.len()),
+                                                                     hx::free_inserter);
+        for (NodeID id : seed) {
+            rc = host.insert(id, *ins);
+            if (rc != HNSW_OK) return rc;
+        }
+        pos = take;
+    }
+    if (pos == order.size()) {
+        host.version++;
+        return HNSW_OK;
+    }
+
+    // ---- device snapshot without the search-only extras ----
+    const int saved_inline = h->dev.inline_rows;
+    h->dev.inline_rows = 0;
+    h->dev.release();
+    rc = h->dev.upload(host, h->device);
+    h->dev.inline_rows = saved_inline;
+    if (rc != HNSW_OK) return rc;
+    h->device = h->dev.device;
+    HIP_TRY(hipSetDevice(h->dev.device));
+    hx::DevView v = h->dev.view;
+    const uint32_t m = (uint32_t)host.params.m, L = host.nb_layers();
+    const uint32_t BMAX = 4096;
+    DevBuf dLevels, dIds, dOutIds, dOutD, dStatus, dRowIdx, dRowData;
+    if ((rc = dLevels.alloc(host.len())) || (rc = dIds.alloc(BMAX * 4)) ||
+        (rc = dOutIds.alloc((size_t)BMAX * L * m * 4)) || (rc = dOutD.alloc((size_t)BMAX * L * m * 4)) ||
+        (rc = dStatus.alloc(BMAX * 4)))
+        return rc;
+    HIP_TRY(hipMemcpy(dLevels.p, host.levels.data(), host.len(), hipMemcpyHostToDevice));
+    std::vector<uint32_t> o_ids((size_t)BMAX * L * m);
+    std::vector<float> o_d((size_t)BMAX * L * m);
+    std::vector<int32_t> o_st(BMAX);
+    size_t row_cap = 0;
+    std::vector<uint32_t> row_idx, row_data;
+    std::vector<std::vector<uint64_t>> dirty_t(nb_threads);
+    hx::DirtyStamps stamps(host.adj0.size(), host.adj_up.size());
+    uint64_t connected = n_before + pos;
+    const auto t_start = std::chrono::steady_clock::now();
+    double t_gpu = 0, t_host = 0, t_sync = 0;
+    size_t n_fallback = 0, n_batches = 0;
+
+    while (pos < order.size()) {
+        const size_t B = std::min<size_t>(order.size() - pos,
+                                          std::min<uint64_t>(BMAX, std::max<uint64_t>(64, connected / 8)));
+        const NodeID *batch = &order[pos];
+        auto t0 = std::chrono::steady_clock::now();
+        HIP_TRY(hipMemcpy(dIds.p, batch, B * 4, hipMemcpyHostToDevice));
+        hx::InsertArgs a{};
+        a.point_ids = dIds.as<uint32_t>();
+        a.levels = dLevels.as<uint8_t>();
+        a.ef_cons = (uint32_t)host.params.ef_cons;
+        a.m = m;
+        a.max_layers = L;
+        a.out_ids = dOutIds.as<uint32_t>();
+        a.out_dists = dOutD.as<float>();
+        a.out_status = dStatus.as<int32_t>();
+        rc = hx::launch_insert(v, a, (uint32_t)B, nullptr);
+        if (rc != HNSW_OK) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(o_ids.data(), dOutIds.p, B * L * m * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(o_d.data(), dOutD.p, B * L * m * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(o_st.data(), dStatus.p, B * 4, hipMemcpyDeviceToHost));
+        auto t1 = std::chrono::steady_clock::now();
+
+        // ---- host: connect the batch (reference semantics), collect the rows that changed ----
+        std::atomic<size_t> next{0};
+        std::atomic<int> err{HNSW_OK};
+        std::vector<NodeID> fallback;
+        std::mutex fb_mu;
+        for (auto &dv : dirty_t) dv.clear();
+        stamps.next_batch();
+        auto work = [&](unsigned t) {
+            std::vector<std::vector<hx::Dist>> nbrs(L);
+            for (size_t i = next.fetch_add(1); i < B && err.load() == HNSW_OK; i = next.fetch_add(1)) {
+                const NodeID p = batch[i];
+                if (o_st[i] != HNSW_OK) {
+                    std::lock_guard<std::mutex> g(fb_mu);
+                    fallback.push_back(p);
+                    continue;
+                }
+                for (uint32_t l = 0; l < L; l++) {
+                    nbrs[l].clear();
+                    for (uint32_t k = 0; k < m; k++) {
+                        const uint32_t id = o_ids[(i * L + l) * m + k];
+                        if (id != UINT32_MAX) nbrs[l].push_back(hx::Dist{id, o_d[(i * L + l) * m + k]});
+                    }
+                }
+                const int r = host.connect_point(p, nbrs, &dirty_t[t]);
+                if (r != HNSW_OK) err.store(r);
+            }
+        };
+        {
+            const unsigned nt = (unsigned)std::min<size_t>(nb_threads, B);
+            if (nt <= 1) {
+                work(0);
+            } else {
+                std::vector<std::thread> th;
+                for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
+                for (auto &t : th) t.join();
+            }
+        }
+        if (err.load() != HNSW_OK) return err.load();
+        if (!fallback.empty()) {  // e.g. visited-table overflow: the CPU path serves those points
+            n_fallback += fallback.size();
+            std::sort(fallback.begin(), fallback.end());
+            std::unique_ptr<hx::Inserter, void (*)(hx::Inserter *)> ins(hx::new_inserter(host.len()),
+                                                                         hx::free_inserter);
+            hx::DirtyScope scope(&dirty_t[0]);
+            for (NodeID p : fallback) {
+                rc = host.insert(p, *ins);
+                if (rc != HNSW_OK) return rc;
+            }
+        }
+        auto t2 = std::chrono::steady_clock::now();
+
+        // ---- changed rows back to HBM (truncated to the stride; the final upload is exact) ----
+        std::vector<uint64_t> dirty0, dirty_up;  // already unique (per-row stamps)
+        for (auto &dv : dirty_t)
+            for (uint64_t key : dv) ((key >> 32) == 0 ? dirty0 : dirty_up).push_back(key);
+        for (int pass = 0; pass < 2; pass++) {  // pass 0: layer 0 rows, pass 1: upper-layer rows
+            const std::vector<uint64_t> &dirty = pass == 0 ? dirty0 : dirty_up;
+            if (dirty.empty()) continue;
+            const uint32_t S = pass == 0 ? v.S0 : v.S1;
+            row_idx.resize(dirty.size());
+            row_data.resize(dirty.size() * (size_t)S);
+            auto pack = [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; i++) {
+                    const uint32_t layer = (uint32_t)(dirty[i] >> 32);
+                    const NodeID id = (NodeID)dirty[i];
+                    const std::vector<NodeID> &r = host.row(layer, id);
+                    row_idx[i] = layer == 0 ? id : host.upper_base[id] + layer - 1;
+                    uint32_t *o = &row_data[i * (size_t)S];
+                    const size_t k = std::min<size_t>(r.size(), S);
+                    std::copy(r.begin(), r.begin() + k, o);
+                    std::fill(o + k, o + S, UINT32_MAX);
+                }
+            };
+            const unsigned nt = (unsigned)std::min<size_t>(nb_threads, std::max<size_t>(1, dirty.size() / 4096));
+            if (nt <= 1) {
+                pack(0, dirty.size());
+            } else {
+                std::vector<std::thread> th;
+                for (unsigned t = 0; t < nt; t++)
+                    th.emplace_back(pack, dirty.size() * t / nt, dirty.size() * (t + 1) / nt);
+                for (auto &t : th) t.join();
+            }
+            if (row_idx.size() > row_cap) {
+                row_cap = row_idx.size() * 2;
+                if (dRowIdx.p) (void)hipFree(dRowIdx.p);
+                if (dRowData.p) (void)hipFree(dRowData.p);
+                dRowIdx.p = dRowData.p = nullptr;
+                if ((rc = dRowIdx.alloc(row_cap * 4)) ||
+                    (rc = dRowData.alloc(row_cap * (size_t)std::max(v.S0, v.S1) * 4)))
+                    return rc;
+            }
+            HIP_TRY(hipMemcpy(dRowIdx.p, row_idx.data(), row_idx.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(dRowData.p, row_data.data(), row_data.size() * 4, hipMemcpyHostToDevice));
+            rc = hx::launch_scatter_rows(pass == 0 ? h->dev.adj0_mut() : h->dev.adj_up_mut(), S,
+                                         dRowIdx.as<uint32_t>(), dRowData.as<uint32_t>(),
+                                         (uint32_t)row_idx.size(), nullptr);
+            if (rc != HNSW_OK) return rc;
+            HIP_TRY(hipDeviceSynchronize());  // the staging buffers are reused by the next pass
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        auto t3 = std::chrono::steady_clock::now();
+        t_gpu += std::chrono::duration<double>(t1 - t0).count();
+        t_host += std::chrono::duration<double>(t2 - t1).count();
+        t_sync += std::chrono::duration<double>(t3 - t2).count();
+        pos += B;
+        connected += B;
+        n_batches++;
+        if (verbose && (n_batches % 16 == 0 || pos == order.size()))
+            fprintf(stderr, "\rBuilding HNSW index on the GPU %zu/%zu", pos, order.size());
+    }
+    if (verbose) {
+        const double tot = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        fprintf(stderr,
+                "\non-device build: %zu batches in %.2f s (insert kernel + copies %.2f s, host connect %.2f s, "
+                "row scatter %.2f s), %zu points took the CPU path\n",
+                n_batches, tot, t_gpu, t_host, t_sync, n_fallback);
+    }
+    host.version++;  // the search snapshot (overflow CSR, inline rows) is rebuilt by the next upload
+    return HNSW_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -233,7 +469,13 @@ int hnsw_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_t
 int hnsw_insert_bulk_levels(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads,
                             int verbose, const uint8_t *levels) {
     if (!h || !rows) return HNSW_ERR_ARG;
+    if (h->gpu_build) return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels);
     return h->host->insert_bulk(rows, n, nb_threads, verbose != 0, levels);
+}
+int hnsw_insert_bulk_device(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads,
+                            int verbose, const uint8_t *levels) {
+    if (!h || !rows) return HNSW_ERR_ARG;
+    return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels);
 }
 int hnsw_insert_vec(hnsw_index *h, const float *v, uint32_t *out_id) {
     return hnsw_insert_vec_level(h, v, -1, out_id);
@@ -559,6 +801,9 @@ int hnsw_set_option(hnsw_index *h, const char *key, int64_t value) {
         h->dev.inline_rows = (int)value;
     } else if (!strcmp(key, "inline_budget_mb")) {
         h->dev.fat_budget_bytes = (uint64_t)value << 20;
+    } else if (!strcmp(key, "gpu_build")) {
+        h->gpu_build = value != 0;
+        return HNSW_OK;
     } else {
         set_error("unknown option %s", key);
         return HNSW_ERR_ARG;

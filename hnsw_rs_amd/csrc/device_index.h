@@ -75,6 +75,17 @@ struct SearchArgs {
     unsigned long long *dbg;     // diagnostic builds only (HX_STAMPS): nq x 6 cycle sums, else null
 };
 
+// one batch of the on-device build: insertion searches for point_ids[0..n) (search_kernels.hip)
+struct InsertArgs {
+    const uint32_t *point_ids;  // device
+    const uint8_t *levels;      // device, level of every stored point
+    uint32_t ef_cons, m;
+    uint32_t max_layers;        // layer slots in the outputs
+    uint32_t *out_ids;          // [n][max_layers][m], padded with 0xFFFFFFFF
+    float *out_dists;           // [n][max_layers][m]
+    int32_t *out_status;        // [n]
+};
+
 class DeviceIndex {
   public:
     ~DeviceIndex() { release(); }
@@ -84,6 +95,10 @@ class DeviceIndex {
     uint64_t fat_budget_bytes = 64ull << 30;
     void release();
     bool current(const HostIndex &idx) const { return valid && version_seen == idx.version; }
+
+    // mutable views of the adjacency arrays (the on-device build scatters dirty rows into them)
+    uint32_t *adj0_mut() { return static_cast<uint32_t *>(bufs_[1]); }
+    uint32_t *adj_up_mut() { return static_cast<uint32_t *>(bufs_[2]); }
 
     bool valid = false;
     int device = -1;
@@ -106,6 +121,10 @@ int launch_search(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint3
                   hipStream_t stream);
 uint32_t default_slots_log2(uint32_t ef);
 uint32_t max_slots_log2(uint32_t ef);
+
+int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipStream_t stream);
+int launch_scatter_rows(uint32_t *dst, uint32_t S, const uint32_t *d_row_index, const uint32_t *d_data,
+                        uint32_t n, hipStream_t stream);
 
 // out[i] = dist(point ids[i], query) for one query; d_q is the raw query (dim floats, device)
 int launch_distance_batch(const DevView &v, const float *d_q, const uint32_t *d_ids, uint64_t k,

@@ -211,6 +211,20 @@ bool HostIndex::degree(uint32_t layer, NodeID id, size_t *out) const {
     return true;
 }
 
+// rows touched by the current thread's connect_point (on-device build): layer << 32 | id.  A
+// per-row stamp (set with an atomic exchange) keeps every row at most once per batch across threads.
+static thread_local std::vector<uint64_t> *tl_dirty = nullptr;
+static std::atomic<uint32_t> *g_stamp0 = nullptr, *g_stamp_up = nullptr;
+static uint32_t g_stamp_epoch = 0;
+static inline void mark_dirty_row(uint32_t layer, NodeID id, size_t up_row) {
+    if (!tl_dirty) return;
+    std::atomic<uint32_t> *st = layer == 0 ? (g_stamp0 ? &g_stamp0[id] : nullptr)
+                                           : (g_stamp_up ? &g_stamp_up[up_row] : nullptr);
+    if (st && st->exchange(g_stamp_epoch, std::memory_order_relaxed) == g_stamp_epoch) return;
+    tl_dirty->push_back(((uint64_t)layer << 32) | id);
+}
+#define mark_dirty(layer, id) mark_dirty_row(layer, id, (layer) == 0 ? 0 : (size_t)upper_base[id] + (layer) - 1)
+
 static inline void row_insert(std::vector<NodeID> &r, NodeID x) {
     if (std::find(r.begin(), r.end(), x) == r.end()) r.push_back(x);
 }
@@ -238,6 +252,8 @@ int HostIndex::add_edge(uint32_t layer, NodeID a, NodeID b) {
     lock_row(layer, b);
     row_insert(row(layer, b), a);
     unlock_row(layer, b);
+    mark_dirty(layer, a);
+    mark_dirty(layer, b);
     return HNSW_OK;
 }
 // Graph::remove_edge, graph.rs:72-83
@@ -249,18 +265,32 @@ int HostIndex::remove_edge(uint32_t layer, NodeID a, NodeID b) {
     lock_row(layer, b);
     row_remove(row(layer, b), a);
     unlock_row(layer, b);
+    mark_dirty(layer, a);
+    mark_dirty(layer, b);
     return HNSW_OK;
 }
-// Graph::isolate_node, graph.rs:85-94: edges to degree-1 neighbours survive
+// Graph::isolate_node, graph.rs:85-94: edges to degree-1 neighbours survive.  The reference reads
+// the neighbour's degree and removes the edge in two unsynchronised steps; with several threads
+// two of them can each see degree 2 and together strip a node of its last edges.  Here the check
+// and the removal happen under both row locks (taken in id order, the only nested locking in the
+// build), which is the same thing on one thread and keeps "min degree > 0" (template.rs:570) true
+// on many.
 int HostIndex::isolate_node(uint32_t layer, NodeID node) {
     std::vector<NodeID> nb;
     if (!neighbors_vec(layer, node, &nb)) return HNSW_ERR_NODE_NOT_IN_GRAPH;
     for (NodeID n : nb) {
-        size_t deg;
-        if (!degree(layer, n, &deg)) return HNSW_ERR_NODE_NOT_IN_GRAPH;
-        if (deg == 1) continue;
-        int rc = remove_edge(layer, node, n);
-        if (rc != HNSW_OK) return rc;
+        if (!in_layer(layer, n)) return HNSW_ERR_NODE_NOT_IN_GRAPH;
+        const NodeID lo = std::min(node, n), hi = std::max(node, n);
+        lock_row(layer, lo);
+        if (hi != lo) lock_row(layer, hi);
+        if (row(layer, n).size() != 1) {
+            row_remove(row(layer, node), n);
+            row_remove(row(layer, n), node);
+            mark_dirty(layer, node);
+            mark_dirty(layer, n);
+        }
+        if (hi != lo) unlock_row(layer, hi);
+        unlock_row(layer, lo);
     }
     return HNSW_OK;
 }
@@ -490,6 +520,11 @@ int HostIndex::insert(NodeID point_id, Inserter &ins) {
     }
     int rc = ins.build_insertion_results(*this, point, levels[point_id]);
     if (rc != HNSW_OK) return rc;
+    return apply_insertion_results(ins);
+}
+
+int HostIndex::apply_insertion_results(Inserter &ins) {
+    int rc = HNSW_OK;
     // make_connections, template.rs:196-207
     for (auto &lr : ins.insertion_results) {
         for (const Dist &n : lr.second.nbrs) {
@@ -532,6 +567,43 @@ int HostIndex::insert(NodeID point_id, Inserter &ins) {
         }
     }
     return HNSW_OK;
+}
+
+Inserter *new_inserter(uint64_t n_points) {
+    Inserter *ins = new Inserter();
+    ins->vstamp.assign(n_points, 0);
+    return ins;
+}
+void free_inserter(Inserter *ins) { delete ins; }
+DirtyScope::DirtyScope(std::vector<uint64_t> *dirty) { tl_dirty = dirty; }
+DirtyScope::~DirtyScope() { tl_dirty = nullptr; }
+
+DirtyStamps::DirtyStamps(size_t n0, size_t n_up) {
+    s0_.reset(new std::atomic<uint32_t>[n0 ? n0 : 1]);
+    sup_.reset(new std::atomic<uint32_t>[n_up ? n_up : 1]);
+    for (size_t i = 0; i < n0; i++) s0_[i].store(0, std::memory_order_relaxed);
+    for (size_t i = 0; i < n_up; i++) sup_[i].store(0, std::memory_order_relaxed);
+    g_stamp0 = s0_.get();
+    g_stamp_up = sup_.get();
+    g_stamp_epoch = 0;
+}
+DirtyStamps::~DirtyStamps() { g_stamp0 = g_stamp_up = nullptr; }
+void DirtyStamps::next_batch() { g_stamp_epoch++; }
+
+int HostIndex::connect_point(NodeID point_id, const std::vector<std::vector<Dist>> &nbrs,
+                             std::vector<uint64_t> *dirty) {
+    if (point_id >= len()) return HNSW_ERR_ARG;
+    Inserter ins;
+    for (size_t l = 0; l < nbrs.size(); l++) {
+        if (nbrs[l].empty()) continue;
+        Inserter::LayerRes lr{point_id, nbrs[l]};
+        std::sort(lr.nbrs.begin(), lr.nbrs.end(), dist_lt);  // BTreeSet<Dist> order
+        ins.insertion_results[l] = std::move(lr);
+    }
+    tl_dirty = dirty;
+    const int rc = apply_insertion_results(ins);
+    tl_dirty = nullptr;
+    return rc;
 }
 
 // HNSW::store_points, template.rs:269-293

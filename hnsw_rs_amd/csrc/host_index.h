@@ -104,6 +104,15 @@ class HostIndex {
     int store_points(const float *rows, uint64_t n, const uint8_t *levels_in,
                      std::vector<NodeID> *ids_out);
     int insert(NodeID point_id, Inserter &ins);
+    // second half of insert (template.rs:185-187): make_connections, prune_connections,
+    // make_pruned_connections for the results held by `ins`
+    int apply_insertion_results(Inserter &ins);
+    // Connect one point from neighbour lists computed elsewhere (the on-device build): nbrs[l] holds
+    // the heuristic's selection for layer l (Dist of each neighbour to the point).  Rows touched are
+    // appended to `dirty` (layer << 32 | id) when it is not null.
+    int connect_point(NodeID point_id, const std::vector<std::vector<Dist>> &nbrs,
+                      std::vector<uint64_t> *dirty);
+    void prepare_build() { ensure_locks(); }
     int insert_bulk(const float *rows, uint64_t n, uint32_t nb_threads, bool verbose,
                     const uint8_t *levels_in);
     int insert_vec(const float *v, int level, NodeID *out_id);
@@ -122,6 +131,26 @@ class HostIndex {
     void ensure_locks();
     mutable std::unique_ptr<std::atomic<uint8_t>[]> lock0_, lock_up_;
     mutable size_t lock0_n_ = 0, lock_up_n_ = 0;
+};
+
+// opaque Inserter handles for code outside host_index.cpp
+Inserter *new_inserter(uint64_t n_points);
+void free_inserter(Inserter *);
+// routes the rows touched by this thread's add_edge / remove_edge into `dirty` while in scope
+struct DirtyScope {
+    explicit DirtyScope(std::vector<uint64_t> *dirty);
+    ~DirtyScope();
+};
+
+// one per on-device build: a stamp per adjacency row so that a row is reported dirty once per batch
+class DirtyStamps {
+  public:
+    DirtyStamps(size_t n_rows0, size_t n_rows_up);
+    ~DirtyStamps();
+    void next_batch();
+
+  private:
+    std::unique_ptr<std::atomic<uint32_t>[]> s0_, sup_;
 };
 
 // persistence (template.rs:43-131)

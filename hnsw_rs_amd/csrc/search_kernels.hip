@@ -266,6 +266,31 @@ __device__ __forceinline__ bool stage_query(const DevView &v, const float *qv, f
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stage a STORED point as the query (build path: Point::dist2other between two stored points,
+// points/src/points.rs:86-93).  QUANT8: the packed row already is in the half-row element order, so
+// yq[h * nq_half + e] = code * delta + min straight from the row.  F32: the row's floats.
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ void stage_row(const DevView &v, uint32_t id, float *yq, int lane) {
+    if (KIND == HNSW_VEC_QUANT8) {
+        const uint32_t nq_half = v.half_bytes - 8;
+        const uint8_t *row = v.rows + (size_t)id * v.row_stride;
+        for (uint32_t i = lane; i < 2 * nq_half; i += 64) {
+            const uint32_t hh = i >= nq_half ? 1u : 0u, e = i - hh * nq_half;
+            const uint8_t *half = row + hh * v.half_bytes;
+            const float mn = *reinterpret_cast<const float *>(half);
+            const float delta = *reinterpret_cast<const float *>(half + 4);
+            const bool used = e < v.nch4 || (hh == 0 && e < v.nch4 + v.rem);
+            yq[i] = used ? ((float)half[8 + e] * delta) + mn : 0.0f;
+        }
+    } else {
+        const float *row = reinterpret_cast<const float *>(v.rows + (size_t)id * v.row_stride);
+        for (uint32_t e = lane; e < v.dim; e += 64) yq[e] = row[e];
+    }
+    wave_fence();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Distance of one stored point to the staged query for ANY dimension (runtime loops): used by
 // the test-seam and brute-force kernels, and by the search kernel when no specialised variant
 // fits.  QUANT8: valid on the even lane of the pair; F32: per lane.
@@ -437,7 +462,8 @@ struct WaveList {
 
     // Merge the wave's candidate keys (KEY_INVALID = none) into the sorted list, keeping the ef
     // smallest: streaming top-ef of searcher.rs:74-94 for a whole batch (order-independent).
-    __device__ __forceinline__ void merge(u64 key, uint32_t ef, u64 *perm, int lane) {
+    // new_flag (0 or KEY_EXPANDED) is OR-ed into every key that enters the list
+    __device__ __forceinline__ void merge(u64 key, uint32_t ef, u64 *perm, int lane, u64 new_flag = 0) {
         const bool full = n_cur >= ef;
         const bool surv = key != KEY_INVALID && (!full || key < last_key);
         u64 smask = __ballot(surv);
@@ -468,7 +494,7 @@ struct WaveList {
                     if (lane == 0) sh = carry;
                     if (R > 1) carry = readlane64(L[r], 63);
                     if (idx == pos)
-                        L[r] = e;
+                        L[r] = e | new_flag;
                     else if (idx > pos)
                         L[r] = sh;
                 }
@@ -506,7 +532,7 @@ struct WaveList {
             const uint32_t np = idx + shift[r];
             if (idx < n_cur && np < ef) perm[np] = L[r];
         }
-        if (surv && my_rank < ef) perm[my_rank] = key;
+        if (surv && my_rank < ef) perm[my_rank] = key | new_flag;
         n_cur = min(n_cur + m, ef);
         wave_fence();  // single-wave workgroup: orders the LDS writes before the reads
 #pragma unroll
@@ -1552,6 +1578,294 @@ hx_search2_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2
             a.out_stats[q] = st;
         }
     }
+}
+
+// =============================================================================================
+// On-device insertion search (HNSW::insert's first half: Inserter::build_insertion_results,
+// hnsw/src/template/inserter.rs:40-126) for a BATCH of already stored points against the current
+// HBM graph, one wave per point:
+//   setup_insert            selected = {(ep, d(ep, p))}                      inserter.rs:53-68
+//   traverse_layers_above   search_layer(ef = 1) for layers > p.level       inserter.rs:70-89
+//   traverse_layers_below   per layer l <= p.level: search_layer(ef_cons), select_heuristic(m,
+//                           extend_cands = keep_pruned = true), save, and the selection seeds the
+//                           next layer                                       inserter.rs:91-126
+// The graph is read-only during a launch: points of one batch do not see each other (the reference's
+// multi-threaded insert_bulk is racy in the same way, template.rs:403-440), so a graph built this
+// way is judged by recall, not by identity with the sequential build.  Deviations, all documented
+// in DESIGN.md: the heuristic's candidate set is capped at the 512 nearest (the reference keeps
+// all of selected ∪ their neighbours); the un-popped heuristic candidates do not leak into the
+// next layer's frontier.  The edges themselves are applied on the host with the
+// reference's make_connections / prune_connections / make_pruned_connections.
+// =============================================================================================
+template <int KIND>
+__global__ void __launch_bounds__(64)
+hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int R = HX_MAX_R;  // list capacity 512: the heuristic's candidate set lives in it
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    const uint32_t p = a.point_ids[b];
+    uint32_t *htab = reinterpret_cast<uint32_t *>(smem);
+    const uint32_t hslots = 1u << slots_log2, hmask = hslots - 1;
+    const uint32_t vis_limit = hslots - (hslots >> 2);
+    u64 *perm = reinterpret_cast<u64 *>(smem + 4ull * hslots);
+    u64 *selk = perm + 64 * R;                                   // [64] selected keys
+    uint32_t *rejpos = reinterpret_cast<uint32_t *>(selk + 64);  // [512] rejected list positions
+    const uint32_t yq_bytes =
+        ((KIND == HNSW_VEC_QUANT8 ? 2u * (v.half_bytes - 8) * 4u : v.dim * 4u) + 15u) & ~15u;
+    float *yq = reinterpret_cast<float *>(rejpos + 512);
+    float *yqe = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(yq) + yq_bytes);
+
+    constexpr int LPC = (KIND == HNSW_VEC_QUANT8) ? 2 : 1;
+    constexpr int CHUNK = 64 / LPC;
+    const int h = (LPC == 2) ? (lane & 1) : 0;
+    const int cslot = lane / LPC;
+    const bool first = (LPC == 1) || (h == 0);
+    int32_t status = HNSW_OK;
+    uint32_t n_vis = 0;
+
+    const uint32_t level = min((uint32_t)a.levels[p], v.nb_layers - 1);
+    const uint32_t m = a.m, ef_cons = max(1u, a.ef_cons);
+    // outputs of this point: [max_layers][m], padded
+    uint32_t *o_ids = a.out_ids + (size_t)b * a.max_layers * m;
+    float *o_d = a.out_dists + (size_t)b * a.max_layers * m;
+    for (uint32_t i = lane; i < a.max_layers * m; i += 64) {
+        o_ids[i] = HX_EMPTY_SLOT;
+        o_d[i] = __builtin_inff();
+    }
+
+    stage_row<KIND>(v, p, yq, lane);
+
+    WaveList<R> wl;
+#pragma unroll
+    for (int r = 0; r < R; r++) wl.L[r] = KEY_INVALID;
+    wl.n_cur = 0;
+    wl.last_key = KEY_INVALID;
+
+    // one pass over up to CHUNK ids: optional visited filter, distance to the staged row, merge
+    auto process = [&](uint32_t id, bool valid, bool visit, uint32_t ef_l, u64 new_flag) {
+        bool fresh = valid;
+        if (visit) {
+            bool f = false;
+            if (valid && first) f = visited_insert(htab, hmask, slots_log2, id);
+            if (LPC == 2) f = (pair_swap_i(f ? 1 : 0) | (f ? 1 : 0)) != 0;
+            fresh = f;
+        }
+        if (__ballot(fresh && first) == 0) return;
+        const float dist = dist_any_dim<KIND>(v, id, fresh, h, yq);
+        u64 key = KEY_INVALID;
+        bool nan = false;
+        if (fresh && first) {
+            nan = dist != dist;
+            if (!nan) key = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | id;
+        }
+        if (__ballot(nan)) status = HNSW_ERR_NAN_INPUT;
+        wl.merge(key, ef_l, perm, lane, new_flag);
+    };
+    // expand every unexpanded entry of the list on `layer` (search_layer's loop, searcher.rs:35-95)
+    auto expand_all = [&](int layer, uint32_t ef_l, u64 new_flag) {
+        const uint32_t S = layer == 0 ? v.S0 : v.S1;
+        while (status == HNSW_OK) {
+            const int cpos = wl.first_unexpanded(lane);
+            if (cpos < 0) break;
+            uint32_t cid = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if ((cpos >> 6) == r) {
+                    cid = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wl.L[r], cpos & 63);
+                    if (lane == (cpos & 63)) wl.L[r] |= KEY_EXPANDED;
+                }
+            }
+            const uint32_t *row;
+            if (layer == 0) {
+                row = v.adj0 + (size_t)cid * S;
+            } else {
+                const uint32_t ub = v.upper_base[cid];
+                if (ub == HX_EMPTY_SLOT) {
+                    status = HNSW_ERR_NODE_NOT_IN_GRAPH;
+                    break;
+                }
+                row = v.adj_up + ((size_t)ub + layer - 1) * S;
+            }
+            for (uint32_t c0 = 0; c0 < S && status == HNSW_OK; c0 += CHUNK) {
+                const uint32_t slot = c0 + cslot;
+                uint32_t nb = HX_EMPTY_SLOT;
+                if (slot < S) nb = row[slot];
+                // during a build the device rows never carry overflow pointers (rows are truncated
+                // to the stride when they are scattered); a flagged id is skipped
+                const bool valid = nb != HX_EMPTY_SLOT && !(nb & HX_OVF_FLAG) && nb != p;
+                const uint32_t cnt = (uint32_t)__popcll(__ballot(valid && first));
+                if (cnt == 0) continue;
+                if (n_vis + cnt > vis_limit) {
+                    status = HNSW_ERR_OVERFLOW;
+                    break;
+                }
+                n_vis += cnt;
+                process(nb, valid, true, ef_l, new_flag);
+            }
+        }
+    };
+    // start a layer: visited.clear(), candidates ∪= selected, visited ∪= ids(selected)
+    auto begin_layer = [&](uint32_t ef_l) {
+        for (uint32_t s = lane; s < (hslots >> 2); s += 64)
+            reinterpret_cast<uint4 *>(htab)[s] =
+                make_uint4(HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT);
+        wave_fence();
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (64u * r + lane < wl.n_cur) {
+                wl.L[r] &= KEY_MASK;
+                visited_insert(htab, hmask, slots_log2, (uint32_t)wl.L[r]);
+            }
+        }
+        n_vis = wl.n_cur;
+        wl.refresh_last(ef_l);
+    };
+
+    if (p == v.ep || p >= v.n_points) status = HNSW_ERR_ARG;  // the host never sends the entry point
+    if (status == HNSW_OK) process(v.ep, lane < LPC, false, 1u, 0);  // setup_insert
+
+    for (int layer = (int)v.nb_layers - 1; status == HNSW_OK && layer >= 0; layer--) {
+        if ((uint32_t)layer > level) {  // traverse_layers_above
+            begin_layer(1u);
+            expand_all(layer, 1u, 0);
+            continue;
+        }
+        // ---- search_layer(ef_cons) ----
+        begin_layer(ef_cons);
+        expand_all(layer, ef_cons, 0);
+        if (status != HNSW_OK) break;
+        // ---- select_heuristic: candidates = selected ∪ neighbours(selected), distances to p
+        // (results.rs:105-146).  Every current entry is expanded once more, this time keeping ALL
+        // distinct neighbours (cap 512 nearest); entries that arrive now are born expanded.
+        begin_layer(64u * R);
+        expand_all(layer, 64u * R, KEY_EXPANDED);
+        if (status != HNSW_OK) break;
+        const uint32_t n_c = wl.n_cur;
+        uint32_t ns = 0, nrej = 0;
+        for (uint32_t i = 0; i < n_c && ns < m; i++) {  // candidates.pop_first() in ascending order
+            u64 ek = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if ((i >> 6) == (uint32_t)r) ek = readlane64(wl.L[r], i & 63) & KEY_MASK;
+            bool accept = true;
+            if (ns > 0) {
+                // nearest selected to e under Dist order: accept iff (d(e,p), e) < (d(e,s), s) for
+                // every selected s (searcher.rs:128-139) -- one ballot, no reduction
+                const uint32_t eid = (uint32_t)ek;
+                stage_row<KIND>(v, eid, yqe, lane);
+                bool worse = false;
+                for (uint32_t s0 = 0; s0 < ns; s0 += CHUNK) {
+                    const uint32_t j = s0 + cslot;
+                    const bool act = j < ns;
+                    const uint32_t sid = act ? (uint32_t)selk[j] : 0u;
+                    const float dist = dist_any_dim<KIND>(v, sid, act, h, yqe);
+                    if (act && first) {
+                        if (dist != dist) status = HNSW_ERR_NAN_INPUT;
+                        const u64 sk = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | sid;
+                        worse |= sk < ek;
+                    }
+                }
+                accept = __ballot(worse) == 0;
+            }
+            if (accept) {
+                if (lane == 0) selk[ns] = ek;
+                ns++;
+            } else {
+                if (lane == 0) rejpos[nrej] = i;
+                nrej++;
+            }
+            wave_fence();
+        }
+        // keep_pruned: fill up from the rejected candidates in ascending order (searcher.rs:141-146)
+        for (uint32_t k = 0; k < nrej && ns < m; k++) {
+            const uint32_t i = rejpos[k];
+            u64 ek = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if ((i >> 6) == (uint32_t)r) ek = readlane64(wl.L[r], i & 63) & KEY_MASK;
+            if (lane == 0) selk[ns] = ek;
+            ns++;
+            wave_fence();
+        }
+        // save_layer_results + the selection seeds the next layer
+        const u64 mine = (uint32_t)lane < ns ? selk[lane] : KEY_INVALID;
+        if ((uint32_t)lane < ns) {
+            o_ids[(size_t)layer * m + lane] = (uint32_t)mine;
+            o_d[(size_t)layer * m + lane] = __builtin_bit_cast(float, (uint32_t)(mine >> 32));
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) wl.L[r] = KEY_INVALID;
+        wl.n_cur = 0;
+        wl.last_key = KEY_INVALID;
+        wl.merge(mine, max(ns, 1u), perm, lane);
+    }
+    if (__ballot(status != HNSW_OK)) {
+        int32_t st = status;
+        for (int o = 32; o > 0; o >>= 1) st = min(st, __shfl_xor(st, o));
+        status = st;
+    }
+    if (lane == 0) a.out_status[b] = status;
+}
+
+// rows[row_index[i]] = data[i] for whole adjacency rows of S slots (dirty rows after a build batch)
+__global__ void __launch_bounds__(64)
+hx_scatter_rows_kernel(uint32_t *dst, uint32_t S, const uint32_t *row_index, const uint32_t *data,
+                       uint32_t n) {
+    const uint32_t i = blockIdx.x;
+    if (i >= n) return;
+    uint32_t *out = dst + (size_t)row_index[i] * S;
+    for (uint32_t k = threadIdx.x; k < S; k += 64) out[k] = data[(size_t)i * S + k];
+}
+
+int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipStream_t stream) {
+    if (nblocks == 0) return HNSW_OK;
+    if (a.m > 32 || a.m == 0 || a.ef_cons > 64 * HX_MAX_R) {
+        set_error("on-device build supports m <= 32 and ef_construction <= 512");
+        return HNSW_ERR_ARG;
+    }
+    const uint32_t slots_log2 = 12 + (a.ef_cons > 64 ? 1 : 0) + (a.ef_cons > 160 ? 1 : 0);
+    const size_t yq_bytes =
+        ((v.kind == HNSW_VEC_QUANT8 ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4) + 15) & ~15ull;
+    const size_t lds = (4ull << slots_log2) + 64ull * HX_MAX_R * 8 + 64 * 8 + 512 * 4 + 2 * yq_bytes;
+    if (lds > 160 * 1024) {
+        set_error("insert kernel needs %zu bytes of LDS", lds);
+        return HNSW_ERR_ARG;
+    }
+    const void *kern = v.kind == HNSW_VEC_QUANT8
+                           ? reinterpret_cast<const void *>(hx_insert_kernel<HNSW_VEC_QUANT8>)
+                           : reinterpret_cast<const void *>(hx_insert_kernel<HNSW_VEC_F32>);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+            return HNSW_ERR_HIP;
+        }
+    }
+    if (v.kind == HNSW_VEC_QUANT8)
+        hipLaunchKernelGGL(hx_insert_kernel<HNSW_VEC_QUANT8>, dim3(nblocks), dim3(64), lds, stream, v, a,
+                           slots_log2);
+    else
+        hipLaunchKernelGGL(hx_insert_kernel<HNSW_VEC_F32>, dim3(nblocks), dim3(64), lds, stream, v, a,
+                           slots_log2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("insert kernel launch: %s", hipGetErrorString(e));
+        return HNSW_ERR_HIP;
+    }
+    return HNSW_OK;
+}
+
+int launch_scatter_rows(uint32_t *dst, uint32_t S, const uint32_t *d_row_index, const uint32_t *d_data,
+                        uint32_t n, hipStream_t stream) {
+    if (n == 0) return HNSW_OK;
+    hipLaunchKernelGGL(hx_scatter_rows_kernel, dim3(n), dim3(64), 0, stream, dst, S, d_row_index, d_data, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("scatter kernel launch: %s", hipGetErrorString(e));
+        return HNSW_ERR_HIP;
+    }
+    return HNSW_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

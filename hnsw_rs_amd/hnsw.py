@@ -161,6 +161,14 @@ class HNSW:
                                               1 if verbose else 0, _p(lv, _u8p)))
         return self
 
+    def insert_bulk_device(self, vectors, nb_threads, verbose, levels=None):
+        """insert_bulk with the insertion searches + heuristic on the GPU (on-device build)"""
+        rows = self._rows(vectors)
+        lv = None if levels is None else np.ascontiguousarray(levels, dtype=np.uint8)
+        check(self._L.hnsw_insert_bulk_device(self._h, _p(rows, _f32p), rows.shape[0], nb_threads,
+                                              1 if verbose else 0, _p(lv, _u8p)))
+        return self
+
     def insert_vec(self, vector, level=None):
         """HNSW::insert_vec(&mut self, &Vec<f32>) -> Result<NodeID, String>"""
         v = self._rows([vector] if not isinstance(vector, np.ndarray) else vector.reshape(1, -1))

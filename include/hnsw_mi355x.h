@@ -105,6 +105,16 @@ int hnsw_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_t
  * reproducible tests pass levels in. */
 int hnsw_insert_bulk_levels(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads,
                             int verbose, const uint8_t *levels);
+/* insert_bulk with the insertion searches on the GPU (on-device build): per
+ * batch one wave per point runs Inserter::build_insertion_results (inserter.rs:40-126: entry point,
+ * greedy descent, search_layer(ef_cons) + select_heuristic per layer) against the graph in HBM; the
+ * host applies make_connections / prune_connections / make_pruned_connections (template.rs:196-251)
+ * on nb_threads threads and the changed adjacency rows are scattered back.  Points of one batch do
+ * not see each other (like the racing threads of the reference's multi-threaded insert_bulk), so
+ * the graph is judged by recall, not by identity with the sequential build.  Needs m <= 32 and
+ * ef_construction <= 512.  hnsw_set_option(h, "gpu_build", 1) routes hnsw_insert_bulk here. */
+int hnsw_insert_bulk_device(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads,
+                            int verbose, const uint8_t *levels);
 /* HNSW::insert_vec(&mut self, &Vec<f32>) -> Result<NodeID, String>, template.rs:165-173 */
 int hnsw_insert_vec(hnsw_index *h, const float *v, uint32_t *out_id);
 int hnsw_insert_vec_level(hnsw_index *h, const float *v, int level /* < 0: draw */, uint32_t *out_id);
@@ -188,7 +198,8 @@ int hnsw_device_bytes(const hnsw_index *h, uint64_t *bytes);
  *   "inline_rows"      -1 auto (default) / 0 never / 1 always: the layer-0 "inline rows" layout (a
  *                      copy of every neighbour's vector row next to the adjacency slot, so that one
  *                      expansion is one coalesced read; costs 2m x the row bytes of HBM)
- *   "inline_budget_mb" largest inline-rows allocation the auto mode accepts (default 65536) */
+ *   "inline_budget_mb" largest inline-rows allocation the auto mode accepts (default 65536)
+ *   "gpu_build"        1: hnsw_insert_bulk(_levels) runs the on-device build */
 int hnsw_set_option(hnsw_index *h, const char *key, int64_t value);
 
 /* ---- harness helpers (not part of the reference's API) --------------------------------------- */

@@ -1,0 +1,21 @@
+"""on-device build vs CPU build at N x 100d: time and recall"""
+import sys, time, os
+sys.path.insert(0, '.')
+import numpy as np
+import hnsw_rs_amd as H
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+kind = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+d, m = 100, 16
+thr = min(32, os.cpu_count())
+vs = H.synth_rows(0, 0x5EED0001, 0, N, d, thr); qs = H.synth_rows(0, 0x5EED0002, 0, 1024, d, 8)
+t = time.time(); dev = H.HNSW.new(m, 32, d, kind).insert_bulk_device(vs, thr, True); t_dev = time.time() - t
+print('device build %.1fs layers=%d compliant=%s' % (t_dev, dev.nb_layers(), dev.assert_param_compliance()), flush=True)
+truth, _ = dev.brute_force(qs, 10)
+for ef in (64, 96):
+    ids, _, _, st = dev.search_batch(qs, 10, ef)
+    print('device-built ef=%d recall %.4f n_dist %.0f' % (ef, sum(len(set(a) & set(b)) for a, b in zip(ids.tolist(), truth.tolist())) / 10240, st[:, 0].mean()), flush=True)
+if len(sys.argv) > 3:
+    t = time.time(); cpu = H.HNSW.new(m, 32, d, kind).insert_bulk(vs, thr, False); print('cpu build %.1fs' % (time.time() - t), flush=True)
+    for ef in (64, 96):
+        ids, _, _, st = cpu.search_batch(qs, 10, ef)
+        print('cpu-built ef=%d recall %.4f n_dist %.0f' % (ef, sum(len(set(a) & set(b)) for a, b in zip(ids.tolist(), truth.tolist())) / 10240, st[:, 0].mean()), flush=True)
