@@ -268,6 +268,11 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
 
 def main():
     args = parse()
+    # Exactly ONE line on stdout: libraries (RCCL prints a version banner) write to fd 1 too, so the
+    # real stdout is set aside for the JSON line and fd 1 points to stderr for everything else.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -382,7 +387,7 @@ def main():
                    "efSearch": ef2, "vec_kind": other, "index_rows": kind_note[other]}
             sec.update(analyse(c, index2, other, tag2, ef2, rec2, ls2, ms2))
             out["quant8_reference_default" if other == "quant8" else "f32_variant"] = sec
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
