@@ -25,7 +25,7 @@ struct hnsw_index {
     std::unique_ptr<hx::HostIndex> host;
     hx::DeviceIndex dev;
     int device = -1;
-    bool gpu_build = false;  // option "gpu_build": insert_bulk runs the on-device build
+    int gpu_build = 0;  // option "gpu_build": insert_bulk runs the on-device build (1 host connect, 2 device connect)
     std::mutex mu;
 };
 
@@ -407,6 +407,348 @@ int gpu_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_th
     return HNSW_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// On-device build, connect step on the GPU as well (option "gpu_build" = 2).  Per batch:
+//   phase 1  hx_insert_kernel  -- as above; additionally writes the new point's own rows and appends
+//                                 one reverse-edge request (target n, source p, layer, d) per selected
+//                                 neighbour
+//   host     sort the requests by (layer, target)                       [a few ms per batch]
+//   phase 2  hx_connect_kernel -- one wave per target row: append, or prune to the cap's nearest;
+//                                 reports the edges that fell out
+//   host     sort the removals by (layer, x)
+//   phase 3  hx_remove_kernel  -- one wave per row that lost a reverse edge (keeps a last edge)
+// Every adjacency row is owned by one wave per phase: no locks, deterministic for a given batch
+// schedule.  The host graph is rebuilt from the device arrays once, at the end.
+// ---------------------------------------------------------------------------------------------
+// The device rows of the full on-device build hold at most `cap` neighbours.  A row the CPU path left
+// longer than that (the reference's transient overflow) is pruned here the way the next
+// prune_connections would: nearest `cap` by (dist, id), reverse edges removed.  Where the dropped
+// edge is the other node's last one it stays on that side (graph.rs:85-94); the pruned side gets it
+// back after the build (`restore`: {x, node, layer, 0}), exactly like a refusal of hx_remove_kernel.
+void clamp_rows_to_cap(hx::HostIndex &host, std::vector<uint4> *restore) {
+    using hx::NodeID;
+    for (uint32_t l = 0; l < host.nb_layers(); l++) {
+        const size_t cap = (size_t)host.layer_m(l);
+        for (NodeID id : host.layer_nodes[l]) {
+            std::vector<NodeID> &row = host.row(l, id);
+            if (row.size() <= cap) continue;
+            hx::PointView a, b;
+            host.get_point(id, &a);
+            std::vector<hx::Dist> ds;
+            for (NodeID x : row) {
+                host.get_point(x, &b);
+                ds.push_back(hx::Dist{x, host.dist2other(a, b)});
+            }
+            std::sort(ds.begin(), ds.end(), hx::dist_lt);
+            for (size_t i = cap; i < ds.size(); i++) {
+                std::vector<NodeID> &back = host.row(l, ds[i].id);
+                if (back.size() == 1 && back[0] == id)
+                    restore->push_back(make_uint4(ds[i].id, id, l, 0));
+                else
+                    back.erase(std::remove(back.begin(), back.end(), id), back.end());
+            }
+            row.clear();
+            for (size_t i = 0; i < cap; i++) row.push_back(ds[i].id);
+        }
+    }
+}
+
+struct ReqRec {
+    uint64_t key;  // layer << 32 | target row's node
+    uint32_t src;
+    uint32_t dbits;
+};
+
+int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads, int verbose,
+                         const uint8_t *levels) {
+    using hx::NodeID;
+    hx::HostIndex &host = *h->host;
+    if (nb_threads == 0) nb_threads = 1;
+    if (host.params.m > 32 || host.params.ef_cons > 512) {
+        set_error("on-device build supports m <= 32 and ef_construction <= 512");
+        return HNSW_ERR_ARG;
+    }
+    const uint64_t n_before = host.len();
+    std::vector<NodeID> ids;
+    int rc = host.store_points(rows, n, levels, &ids);
+    if (rc != HNSW_OK) return rc;
+    host.prepare_build();
+    std::vector<NodeID> order;
+    order.reserve(ids.size());
+    for (NodeID id : ids)
+        if (id != host.params.ep) order.push_back(id);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](NodeID x, NodeID y) { return host.levels[x] > host.levels[y]; });
+    const uint64_t SEED = 2048;
+    size_t pos = 0;
+    if (n_before < SEED) {
+        const size_t take = std::min<size_t>(order.size(), SEED - n_before);
+        std::unique_ptr<hx::Inserter, void (*)(hx::Inserter *)> ins(hx::new_inserter(host.len()),
+                                                                     hx::free_inserter);
+        for (size_t i = 0; i < take; i++) {
+            rc = host.insert(order[i], *ins);
+            if (rc != HNSW_OK) return rc;
+        }
+        pos = take;
+    }
+    if (pos == order.size()) {
+        host.version++;
+        return HNSW_OK;
+    }
+    const auto t_start = std::chrono::steady_clock::now();
+    std::vector<uint4> restore;
+    clamp_rows_to_cap(host, &restore);
+    const int saved_inline = h->dev.inline_rows;
+    h->dev.inline_rows = 0;
+    h->dev.release();
+    rc = h->dev.upload(host, h->device);
+    h->dev.inline_rows = saved_inline;
+    if (rc != HNSW_OK) return rc;
+    h->device = h->dev.device;
+    HIP_TRY(hipSetDevice(h->dev.device));
+    hx::DevView v = h->dev.view;
+    const uint32_t m = (uint32_t)host.params.m, L = host.nb_layers();
+    const uint32_t BMAX = 8192;
+    const uint32_t REQ_CAP = BMAX * m * 2;  // a point has 1 + 1/(m-1) layers on average
+    DevBuf dLevels, dIds, dOutIds, dOutD, dStatus, dReq, dCnt, dGrpT, dGrpL, dGrpOff, dSrc, dSrcD, dRem, dRef;
+    if ((rc = dLevels.alloc(host.len())) || (rc = dIds.alloc(BMAX * 4)) ||
+        (rc = dOutIds.alloc((size_t)BMAX * L * m * 4)) || (rc = dOutD.alloc((size_t)BMAX * L * m * 4)) ||
+        (rc = dStatus.alloc(BMAX * 4)) || (rc = dReq.alloc((size_t)REQ_CAP * 16)) || (rc = dCnt.alloc(64)) ||
+        (rc = dGrpT.alloc((size_t)REQ_CAP * 4)) || (rc = dGrpL.alloc((size_t)REQ_CAP * 4)) ||
+        (rc = dGrpOff.alloc((size_t)(REQ_CAP + 1) * 4)) || (rc = dSrc.alloc((size_t)REQ_CAP * 4)) ||
+        (rc = dSrcD.alloc((size_t)REQ_CAP * 4)) || (rc = dRem.alloc((size_t)REQ_CAP * 16)) ||
+        (rc = dRef.alloc((size_t)REQ_CAP * 16)))
+        return rc;
+    HIP_TRY(hipMemcpy(dLevels.p, host.levels.data(), host.len(), hipMemcpyHostToDevice));
+    // counters: [0] requests, [1] removals, [2] refusals (accumulates over the build), [3] status
+    uint32_t *cnt = dCnt.as<uint32_t>();
+    HIP_TRY(hipMemset(dCnt.p, 0, 64));
+    std::vector<int32_t> o_st(BMAX);
+    std::vector<uint4> recs(REQ_CAP);
+    std::vector<ReqRec> sorted;
+    std::vector<uint32_t> g_t, g_l, g_off, g_src, g_d;
+    std::vector<NodeID> failed;
+    uint64_t connected = n_before + pos;
+    double t_ins = 0, t_host = 0, t_conn = 0;
+    size_t n_batches = 0, n_req = 0, n_rem = 0;
+
+    // groups the records by key and ships them; returns the number of groups
+    auto ship_groups = [&](size_t count, bool with_dists) -> long {
+        std::sort(sorted.begin(), sorted.begin() + count,
+                  [](const ReqRec &x, const ReqRec &y) { return x.key < y.key || (x.key == y.key && x.src < y.src); });
+        g_t.clear(); g_l.clear(); g_off.clear();
+        g_src.resize(count);
+        g_d.resize(count);
+        for (size_t i = 0; i < count; i++) {
+            if (i == 0 || sorted[i].key != sorted[i - 1].key) {
+                g_t.push_back((uint32_t)sorted[i].key);
+                g_l.push_back((uint32_t)(sorted[i].key >> 32));
+                g_off.push_back((uint32_t)i);
+            }
+            g_src[i] = sorted[i].src;
+            g_d[i] = sorted[i].dbits;
+        }
+        g_off.push_back((uint32_t)count);
+        const size_t G = g_t.size();
+        if (G == 0) return 0;
+        if (hipMemcpy(dGrpT.p, g_t.data(), G * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dGrpL.p, g_l.data(), G * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dGrpOff.p, g_off.data(), (G + 1) * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(dSrc.p, g_src.data(), count * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            (with_dists && hipMemcpy(dSrcD.p, g_d.data(), count * 4, hipMemcpyHostToDevice) != hipSuccess)) {
+            set_error("on-device build: copy of the request groups failed");
+            return -1;
+        }
+        return (long)G;
+    };
+
+    while (pos < order.size()) {
+        const size_t B = std::min<size_t>(order.size() - pos,
+                                          std::min<uint64_t>(BMAX, std::max<uint64_t>(64, connected / 8)));
+        const NodeID *batch = &order[pos];
+        auto t0 = std::chrono::steady_clock::now();
+        HIP_TRY(hipMemcpy(dIds.p, batch, B * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(dCnt.p, 0, 8));  // requests, removals
+        hx::InsertArgs a{};
+        a.point_ids = dIds.as<uint32_t>();
+        a.levels = dLevels.as<uint8_t>();
+        a.ef_cons = (uint32_t)host.params.ef_cons;
+        a.m = m;
+        a.max_layers = L;
+        a.out_ids = dOutIds.as<uint32_t>();
+        a.out_dists = dOutD.as<float>();
+        a.out_status = dStatus.as<int32_t>();
+        a.adj0_mut = h->dev.adj0_mut();
+        a.adj_up_mut = h->dev.adj_up_mut();
+        a.req = dReq.as<uint4>();
+        a.req_count = cnt + 0;
+        a.req_cap = REQ_CAP;
+        rc = hx::launch_insert(v, a, (uint32_t)B, nullptr);
+        if (rc != HNSW_OK) return rc;
+        uint32_t counts[4];
+        HIP_TRY(hipMemcpy(counts, dCnt.p, 16, hipMemcpyDeviceToHost));  // synchronises
+        HIP_TRY(hipMemcpy(o_st.data(), dStatus.p, B * 4, hipMemcpyDeviceToHost));
+        size_t nreq = std::min<uint32_t>(counts[0], REQ_CAP);
+        HIP_TRY(hipMemcpy(recs.data(), dReq.p, nreq * 16, hipMemcpyDeviceToHost));
+        auto t1 = std::chrono::steady_clock::now();
+
+        // requests of points that failed (visited-table overflow, request buffer full) are dropped:
+        // those points take the CPU path after the build
+        bool any_failed = false;
+        for (size_t i = 0; i < B; i++)
+            if (o_st[i] != HNSW_OK) {
+                failed.push_back(batch[i]);
+                any_failed = true;
+            }
+        std::vector<NodeID> failed_sorted;
+        if (any_failed) {
+            failed_sorted = failed;
+            std::sort(failed_sorted.begin(), failed_sorted.end());
+        }
+        sorted.resize(std::max(sorted.size(), nreq));
+        size_t cnt_ok = 0;
+        for (size_t i = 0; i < nreq; i++) {
+            const uint4 &r = recs[i];
+            if (any_failed && std::binary_search(failed_sorted.begin(), failed_sorted.end(), r.y)) continue;
+            if (r.x >= host.len() || r.y >= host.len() || r.z > host.levels[r.x] || r.z > host.levels[r.y]) {
+                set_error("on-device build: malformed request (target %u, source %u, layer %u) in batch %zu",
+                          r.x, r.y, r.z, n_batches);
+                return HNSW_ERR_NODE_NOT_IN_GRAPH;
+            }
+            sorted[cnt_ok++] = ReqRec{((uint64_t)r.z << 32) | r.x, r.y, r.w};
+        }
+        long G = ship_groups(cnt_ok, true);
+        if (G < 0) return HNSW_ERR_HIP;
+        n_req += cnt_ok;
+        auto t2 = std::chrono::steady_clock::now();
+        hx::ConnectArgs ca{};
+        ca.grp_target = dGrpT.as<uint32_t>();
+        ca.grp_layer = dGrpL.as<uint32_t>();
+        ca.grp_off = dGrpOff.as<uint32_t>();
+        ca.src_ids = dSrc.as<uint32_t>();
+        ca.src_dists = dSrcD.as<float>();
+        ca.m = m;
+        ca.adj0_mut = h->dev.adj0_mut();
+        ca.adj_up_mut = h->dev.adj_up_mut();
+        ca.out = dRem.as<uint4>();
+        ca.out_count = cnt + 1;
+        ca.out_cap = REQ_CAP;
+        ca.status = reinterpret_cast<int32_t *>(cnt + 3);
+        rc = hx::launch_connect(v, ca, (uint32_t)G, nullptr);
+        if (rc != HNSW_OK) return rc;
+        HIP_TRY(hipMemcpy(counts, dCnt.p, 16, hipMemcpyDeviceToHost));
+        if (counts[3] != 0) {
+            set_error("on-device build: connect kernel reported status %d in batch %zu", (int)counts[3], n_batches);
+            return (int)counts[3];
+        }
+        const size_t nrem = counts[1];
+        auto t3 = std::chrono::steady_clock::now();
+        if (nrem) {
+            HIP_TRY(hipMemcpy(recs.data(), dRem.p, nrem * 16, hipMemcpyDeviceToHost));
+            sorted.resize(std::max(sorted.size(), nrem));
+            for (size_t i = 0; i < nrem; i++) {
+                if (recs[i].x >= host.len() || recs[i].z > host.levels[recs[i].x]) {
+                    set_error("on-device build: malformed removal (row %u, drops %u, layer %u) in batch %zu",
+                              recs[i].x, recs[i].y, recs[i].z, n_batches);
+                    return HNSW_ERR_NODE_NOT_IN_GRAPH;
+                }
+                sorted[i] = ReqRec{((uint64_t)recs[i].z << 32) | recs[i].x, recs[i].y, 0};
+            }
+            G = ship_groups(nrem, false);
+            if (G < 0) return HNSW_ERR_HIP;
+            auto t4 = std::chrono::steady_clock::now();
+            t_host += std::chrono::duration<double>(t4 - t3).count();
+            ca.out = dRef.as<uint4>();
+            ca.out_count = cnt + 2;
+            rc = hx::launch_remove(v, ca, (uint32_t)G, nullptr);
+            if (rc != HNSW_OK) return rc;
+            HIP_TRY(hipDeviceSynchronize());
+            t_conn += std::chrono::duration<double>(std::chrono::steady_clock::now() - t4).count();
+            n_rem += nrem;
+        }
+        t_ins += std::chrono::duration<double>(t1 - t0).count();
+        t_host += std::chrono::duration<double>(t2 - t1).count();
+        t_conn += std::chrono::duration<double>(t3 - t2).count();
+        pos += B;
+        connected += B;
+        n_batches++;
+        if (verbose && (n_batches % 16 == 0 || pos == order.size()))
+            fprintf(stderr, "\rBuilding HNSW index on the GPU %zu/%zu", pos, order.size());
+    }
+
+    // ---- the host graph from the device arrays ----
+    const auto t_sync0 = std::chrono::steady_clock::now();
+    uint32_t counts[4];
+    HIP_TRY(hipMemcpy(counts, dCnt.p, 16, hipMemcpyDeviceToHost));
+    if (counts[3] != 0 || counts[2] > REQ_CAP) {
+        set_error("on-device build: refusal buffer overflow");
+        return HNSW_ERR_OVERFLOW;
+    }
+    std::vector<uint4> refusals(counts[2]);
+    if (counts[2]) HIP_TRY(hipMemcpy(refusals.data(), dRef.p, (size_t)counts[2] * 16, hipMemcpyDeviceToHost));
+    {
+        std::vector<uint32_t> buf;
+        for (int pass = 0; pass < 2; pass++) {
+            std::vector<std::vector<NodeID>> &rowsv = pass == 0 ? host.adj0 : host.adj_up;
+            const uint32_t S = pass == 0 ? v.S0 : v.S1;
+            const size_t R = rowsv.size();
+            if (R == 0) continue;
+            buf.resize(R * (size_t)S);
+            HIP_TRY(hipMemcpy(buf.data(), pass == 0 ? h->dev.adj0_mut() : h->dev.adj_up_mut(), R * (size_t)S * 4,
+                              hipMemcpyDeviceToHost));
+            auto fill = [&](size_t lo, size_t hi) {
+                for (size_t r = lo; r < hi; r++) {
+                    const uint32_t *src = &buf[r * (size_t)S];
+                    std::vector<NodeID> &dst = rowsv[r];
+                    dst.clear();
+                    for (uint32_t k = 0; k < S; k++)
+                        if (src[k] != UINT32_MAX) dst.push_back(src[k]);
+                }
+            };
+            const unsigned nt = (unsigned)std::min<size_t>(nb_threads, std::max<size_t>(1, R / 65536));
+            if (nt <= 1) {
+                fill(0, R);
+            } else {
+                std::vector<std::thread> th;
+                for (unsigned t = 0; t < nt; t++) th.emplace_back(fill, R * t / nt, R * (t + 1) / nt);
+                for (auto &t : th) t.join();
+            }
+        }
+    }
+    // an edge x -> nb that stayed because it was x's last one: restore nb -> x (graph.rs:85-94 keeps both)
+    refusals.insert(refusals.end(), restore.begin(), restore.end());
+    for (const uint4 &r : refusals) {
+        std::vector<NodeID> &row = host.row(r.z, r.y);
+        const std::vector<NodeID> &back = host.row(r.z, r.x);
+        if (std::find(back.begin(), back.end(), r.y) != back.end() &&
+            std::find(row.begin(), row.end(), r.x) == row.end())
+            row.push_back(r.x);
+    }
+    // points the kernel could not serve: their partial rows are cleared, then the CPU path inserts them
+    if (!failed.empty()) {
+        std::sort(failed.begin(), failed.end());
+        for (NodeID p : failed)
+            for (uint32_t l = 0; l <= host.levels[p]; l++) host.row(l, p).clear();
+        std::unique_ptr<hx::Inserter, void (*)(hx::Inserter *)> ins(hx::new_inserter(host.len()),
+                                                                     hx::free_inserter);
+        for (NodeID p : failed) {
+            rc = host.insert(p, *ins);
+            if (rc != HNSW_OK) return rc;
+        }
+    }
+    if (verbose) {
+        const double tot = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        const double t_sync = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_sync0).count();
+        fprintf(stderr,
+                "\non-device build (device connect): %zu batches in %.2f s (insert kernel %.2f s, host grouping "
+                "%.2f s, connect/remove kernels %.2f s, graph read-back %.2f s); %zu requests, %zu removals, "
+                "%u kept-last-edge, %zu points took the CPU path\n",
+                n_batches, tot, t_ins, t_host, t_conn, t_sync, n_req, n_rem, counts[2], failed.size());
+    }
+    host.version++;
+    return HNSW_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -469,13 +811,15 @@ int hnsw_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_t
 int hnsw_insert_bulk_levels(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads,
                             int verbose, const uint8_t *levels) {
     if (!h || !rows) return HNSW_ERR_ARG;
+    if (h->gpu_build == 2) return gpu_insert_bulk_full(h, rows, n, nb_threads, verbose, levels);
     if (h->gpu_build) return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels);
     return h->host->insert_bulk(rows, n, nb_threads, verbose != 0, levels);
 }
 int hnsw_insert_bulk_device(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads,
                             int verbose, const uint8_t *levels) {
     if (!h || !rows) return HNSW_ERR_ARG;
-    return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels);
+    if (h->gpu_build == 1) return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels);
+    return gpu_insert_bulk_full(h, rows, n, nb_threads, verbose, levels);
 }
 int hnsw_insert_vec(hnsw_index *h, const float *v, uint32_t *out_id) {
     return hnsw_insert_vec_level(h, v, -1, out_id);
@@ -802,7 +1146,7 @@ int hnsw_set_option(hnsw_index *h, const char *key, int64_t value) {
     } else if (!strcmp(key, "inline_budget_mb")) {
         h->dev.fat_budget_bytes = (uint64_t)value << 20;
     } else if (!strcmp(key, "gpu_build")) {
-        h->gpu_build = value != 0;
+        h->gpu_build = (int)value;
         return HNSW_OK;
     } else {
         set_error("unknown option %s", key);

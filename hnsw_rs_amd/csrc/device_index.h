@@ -84,6 +84,25 @@ struct InsertArgs {
     uint32_t *out_ids;          // [n][max_layers][m], padded with 0xFFFFFFFF
     float *out_dists;           // [n][max_layers][m]
     int32_t *out_status;        // [n]
+    // full on-device connect (optional, all null otherwise): the kernel writes the point's own rows
+    // and appends one reverse-edge request per selected neighbour
+    uint32_t *adj0_mut, *adj_up_mut;
+    uint4 *req;                 // {target, source, layer, dist bits}
+    uint32_t *req_count;
+    uint32_t req_cap;
+};
+
+// phase 2 / 3 of the on-device connect: groups of requests that share a (layer, target) row
+struct ConnectArgs {
+    const uint32_t *grp_target, *grp_layer, *grp_off;  // n_groups (+1 for off)
+    const uint32_t *src_ids;                           // sources (phase 2) / neighbours to drop (phase 3)
+    const float *src_dists;                            // phase 2 only
+    uint32_t m;
+    uint32_t *adj0_mut, *adj_up_mut;
+    uint4 *out;                                        // phase 2: removals {x, n, layer, 0}; phase 3: refusals
+    uint32_t *out_count;
+    uint32_t out_cap;
+    int32_t *status;                                   // single word, set on overflow of `out`
 };
 
 class DeviceIndex {
@@ -123,6 +142,8 @@ uint32_t default_slots_log2(uint32_t ef);
 uint32_t max_slots_log2(uint32_t ef);
 
 int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipStream_t stream);
+int launch_connect(const DevView &v, const ConnectArgs &a, uint32_t n_groups, hipStream_t stream);
+int launch_remove(const DevView &v, const ConnectArgs &a, uint32_t n_groups, hipStream_t stream);
 int launch_scatter_rows(uint32_t *dst, uint32_t S, const uint32_t *d_row_index, const uint32_t *d_data,
                         uint32_t n, hipStream_t stream);
 

@@ -1794,6 +1794,20 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
             o_ids[(size_t)layer * m + lane] = (uint32_t)mine;
             o_d[(size_t)layer * m + lane] = __builtin_bit_cast(float, (uint32_t)(mine >> 32));
         }
+        if (a.req != nullptr) {
+            // on-device connect: this point's own row (nobody can reach p yet) and one reverse-edge
+            // request per selected neighbour
+            const uint32_t S = layer == 0 ? v.S0 : v.S1;
+            uint32_t *row = layer == 0 ? a.adj0_mut + (size_t)p * S
+                                       : a.adj_up_mut + ((size_t)v.upper_base[p] + layer - 1) * S;
+            for (uint32_t k = lane; k < S; k += 64) row[k] = k < ns ? (uint32_t)selk[k] : HX_EMPTY_SLOT;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(a.req_count, ns);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if ((uint32_t)lane < ns && base + lane < a.req_cap)
+                a.req[base + lane] = make_uint4((uint32_t)mine, p, (uint32_t)layer, (uint32_t)(mine >> 32));
+            if (base + ns > a.req_cap) status = HNSW_ERR_OVERFLOW;
+        }
 #pragma unroll
         for (int r = 0; r < R; r++) wl.L[r] = KEY_INVALID;
         wl.n_cur = 0;
@@ -1851,6 +1865,182 @@ int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipSt
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("insert kernel launch: %s", hipGetErrorString(e));
+        return HNSW_ERR_HIP;
+    }
+    return HNSW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// On-device connect, phase 2: one wave per (layer, target) row that received reverse-edge requests
+// in this batch.  make_connections adds the sources (template.rs:196-207); a row that would exceed
+// the layer's cap is pruned to its `cap` nearest by (dist, id) (prune_connections / select_simple,
+// template.rs:209-238,614-621) -- distances of the existing neighbours are evaluated here, the
+// sources bring d(p, n) = d(n, p).  Every dropped neighbour x (and every source that did not make
+// it) is reported so that phase 3 removes the reverse edge (remove_edge is symmetric,
+// graph.rs:72-83).  Rows are owned by exactly one wave per phase: no locks, no atomics on rows.
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ void __launch_bounds__(64)
+hx_connect_kernel(const DevView v, const ConnectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *perm = reinterpret_cast<u64 *>(smem);       // [64]
+    u64 *ekeys = perm + 64;                           // [64] keys of the existing neighbours
+    float *yq = reinterpret_cast<float *>(ekeys + 64);
+    const int lane = threadIdx.x;
+    const uint32_t g = blockIdx.x;
+    const uint32_t n = a.grp_target[g], layer = a.grp_layer[g];
+    const uint32_t lo = a.grp_off[g], k = a.grp_off[g + 1] - lo;
+    const uint32_t S = layer == 0 ? v.S0 : v.S1;
+    const uint32_t cap = layer == 0 ? 2 * a.m : a.m;
+    if (n >= v.n_points || layer >= v.nb_layers || (layer > 0 && v.upper_base[n] == HX_EMPTY_SLOT)) {
+        *a.status = HNSW_ERR_NODE_NOT_IN_GRAPH;  // a malformed group: never touch memory for it
+        return;
+    }
+    uint32_t *row = layer == 0 ? a.adj0_mut + (size_t)n * S
+                               : a.adj_up_mut + ((size_t)v.upper_base[n] + layer - 1) * S;
+    constexpr int LPC = (KIND == HNSW_VEC_QUANT8) ? 2 : 1;
+    constexpr int CHUNK = 64 / LPC;
+    const int h = (LPC == 2) ? (lane & 1) : 0;
+    const int cslot = lane / LPC;
+    const bool first = (LPC == 1) || (h == 0);
+
+    const uint32_t cur = (uint32_t)lane < S ? row[lane] : HX_EMPTY_SLOT;
+    const bool has = cur != HX_EMPTY_SLOT;
+    const u64 hm = __ballot(has);
+    const uint32_t deg = (uint32_t)__popcll(hm);
+    if (deg + k <= cap && deg + k <= S) {  // room for every source: append
+        // compact the existing ids to the front, then the sources
+        const uint32_t pos = (uint32_t)__popcll(hm & ((1ull << lane) - 1));
+        wave_fence();
+        if (has) row[pos] = cur;
+        for (uint32_t j = lane; j < k; j += 64) row[deg + j] = a.src_ids[lo + j];
+        for (uint32_t j = deg + k + lane; j < S; j += 64) row[j] = HX_EMPTY_SLOT;
+        return;
+    }
+    // ---- prune: keep the `cap` nearest of existing ∪ sources ----
+    stage_row<KIND>(v, n, yq, lane);
+    WaveList<1> wl;
+    wl.L[0] = KEY_INVALID;
+    wl.n_cur = 0;
+    wl.last_key = KEY_INVALID;
+    ekeys[lane] = KEY_INVALID;
+    wave_fence();
+    for (uint32_t c0 = 0; c0 < S; c0 += CHUNK) {  // existing neighbours, CHUNK at a time
+        const uint32_t slot = c0 + cslot;
+        const uint32_t id = (uint32_t)__shfl((int)cur, (int)(slot & 63));
+        const bool act = slot < S && id < v.n_points;
+        if (slot < S && id != HX_EMPTY_SLOT && id >= v.n_points) *a.status = HNSW_ERR_NODE_NOT_IN_GRAPH;
+        const float dist = dist_any_dim<KIND>(v, id, act, h, yq);
+        u64 key = KEY_INVALID;
+        if (act && first) {
+            key = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | id;
+            ekeys[slot] = key;
+        }
+        wl.merge(key, cap, perm, lane);
+    }
+    for (uint32_t j0 = 0; j0 < k; j0 += 64) {  // the sources
+        const uint32_t j = j0 + lane;
+        u64 key = KEY_INVALID;
+        if (j < k) key = ((u64)__builtin_bit_cast(uint32_t, a.src_dists[lo + j]) << 32) | a.src_ids[lo + j];
+        wl.merge(key, cap, perm, lane);
+    }
+    wave_fence();
+    // the new row
+    if ((uint32_t)lane < S) row[lane] = (uint32_t)lane < wl.n_cur ? (uint32_t)wl.L[0] : HX_EMPTY_SLOT;
+    // report what fell out: key > the last kept key (keys are distinct)
+    const u64 lastk = wl.n_cur >= cap ? wl.last_key : KEY_INVALID;
+    auto emit = [&](u64 key) {
+        const bool drop = key != KEY_INVALID && key > lastk;
+        const u64 dm = __ballot(drop);
+        if (dm == 0) return;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.out_count, (uint32_t)__popcll(dm));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const uint32_t at = base + (uint32_t)__popcll(dm & ((1ull << lane) - 1));
+        if (drop) {
+            if (at < a.out_cap)
+                a.out[at] = make_uint4((uint32_t)key, n, layer, 0);
+            else
+                *a.status = HNSW_ERR_OVERFLOW;
+        }
+    };
+    emit(ekeys[lane]);
+    for (uint32_t j0 = 0; j0 < k; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        u64 key = KEY_INVALID;
+        if (j < k) key = ((u64)__builtin_bit_cast(uint32_t, a.src_dists[lo + j]) << 32) | a.src_ids[lo + j];
+        emit(key);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// On-device connect, phase 3: one wave per (layer, x) row that must drop neighbours because they
+// dropped x in phase 2.  An edge to x's LAST neighbour is kept (isolate_node, graph.rs:85-94): such
+// a refusal is reported and the host restores the reverse direction after the build.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+hx_remove_kernel(const DevView v, const ConnectArgs a) {
+    const int lane = threadIdx.x;
+    const uint32_t g = blockIdx.x;
+    const uint32_t x = a.grp_target[g], layer = a.grp_layer[g];
+    const uint32_t lo = a.grp_off[g], k = a.grp_off[g + 1] - lo;
+    const uint32_t S = layer == 0 ? v.S0 : v.S1;
+    if (x >= v.n_points || layer >= v.nb_layers || (layer > 0 && v.upper_base[x] == HX_EMPTY_SLOT)) {
+        *a.status = HNSW_ERR_NODE_NOT_IN_GRAPH;
+        return;
+    }
+    uint32_t *row = layer == 0 ? a.adj0_mut + (size_t)x * S
+                               : a.adj_up_mut + ((size_t)v.upper_base[x] + layer - 1) * S;
+    uint32_t cur = (uint32_t)lane < S ? row[lane] : HX_EMPTY_SLOT;
+    uint32_t deg = (uint32_t)__popcll(__ballot(cur != HX_EMPTY_SLOT));
+    for (uint32_t j = 0; j < k; j++) {
+        const uint32_t nb = a.src_ids[lo + j];
+        const u64 hit = __ballot(cur == nb);
+        if (hit == 0) continue;
+        if (deg == 1) {  // the last edge stays
+            if (lane == 0) {
+                const uint32_t at = atomicAdd(a.out_count, 1u);
+                if (at < a.out_cap)
+                    a.out[at] = make_uint4(x, nb, layer, 0);
+                else
+                    *a.status = HNSW_ERR_OVERFLOW;
+            }
+            continue;
+        }
+        if (cur == nb) cur = HX_EMPTY_SLOT;
+        deg--;
+    }
+    // compact: survivors to the front, every slot written by exactly one lane
+    const u64 hm = __ballot(cur != HX_EMPTY_SLOT);
+    const uint32_t pos = (uint32_t)__popcll(hm & ((1ull << lane) - 1));
+    const uint32_t left = (uint32_t)__popcll(hm);
+    if (cur != HX_EMPTY_SLOT) row[pos] = cur;
+    if ((uint32_t)lane >= left && (uint32_t)lane < S) row[lane] = HX_EMPTY_SLOT;
+}
+
+int launch_connect(const DevView &v, const ConnectArgs &a, uint32_t n_groups, hipStream_t stream) {
+    if (n_groups == 0) return HNSW_OK;
+    const size_t yq_bytes =
+        ((v.kind == HNSW_VEC_QUANT8 ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4) + 15) & ~15ull;
+    const size_t lds = 2 * 64 * 8 + yq_bytes;
+    if (v.kind == HNSW_VEC_QUANT8)
+        hipLaunchKernelGGL(hx_connect_kernel<HNSW_VEC_QUANT8>, dim3(n_groups), dim3(64), lds, stream, v, a);
+    else
+        hipLaunchKernelGGL(hx_connect_kernel<HNSW_VEC_F32>, dim3(n_groups), dim3(64), lds, stream, v, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("connect kernel launch: %s", hipGetErrorString(e));
+        return HNSW_ERR_HIP;
+    }
+    return HNSW_OK;
+}
+
+int launch_remove(const DevView &v, const ConnectArgs &a, uint32_t n_groups, hipStream_t stream) {
+    if (n_groups == 0) return HNSW_OK;
+    hipLaunchKernelGGL(hx_remove_kernel, dim3(n_groups), dim3(64), 0, stream, v, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("remove kernel launch: %s", hipGetErrorString(e));
         return HNSW_ERR_HIP;
     }
     return HNSW_OK;

@@ -8,7 +8,9 @@ kind = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 d, m = 100, 16
 thr = min(32, os.cpu_count())
 vs = H.synth_rows(0, 0x5EED0001, 0, N, d, thr); qs = H.synth_rows(0, 0x5EED0002, 0, 1024, d, 8)
-t = time.time(); dev = H.HNSW.new(m, 32, d, kind).insert_bulk_device(vs, thr, True); t_dev = time.time() - t
+mode = int(os.environ.get('MODE', '2'))
+dev = H.HNSW.new(m, 32, d, kind); dev.set_option('gpu_build', mode)
+t = time.time(); dev.insert_bulk_device(vs, thr, True); t_dev = time.time() - t
 print('device build %.1fs layers=%d compliant=%s' % (t_dev, dev.nb_layers(), dev.assert_param_compliance()), flush=True)
 truth, _ = dev.brute_force(qs, 10)
 for ef in (64, 96):

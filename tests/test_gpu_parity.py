@@ -317,13 +317,23 @@ def test_host_pointer_batch_api_matches_single_queries(glove):
 # on-device build: judged by recall and graph invariants, not by identity
 # ---------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
-def gpu_built():
+def build_inputs():
     n, d, m = 30000, 100, 16
     vs = H.synth_rows(0, 0x5EED0001, 0, n, d)
     qs = H.synth_rows(0, 0x5EED0002, 0, 256, d)
     lv = O.draw_levels(n, m, 0x5EED0003)
-    dev = H.HNSW.new(m, 32, d).insert_bulk_device(vs, 8, False, levels=lv)
     cpu = H.HNSW.new(m, 32, d).insert_bulk(vs, 8, False, levels=lv)
+    return cpu, vs, qs, lv
+
+
+# connect step on the host (1: the reference's make_connections / prune on CPU threads) or on the
+# device (2: request / prune / remove kernels)
+@pytest.fixture(scope="module", params=[1, 2], ids=["host-connect", "device-connect"])
+def gpu_built(request, build_inputs):
+    cpu, vs, qs, lv = build_inputs
+    dev = H.HNSW.new(16, 32, 100)
+    dev.set_option("gpu_build", request.param)
+    dev.insert_bulk_device(vs, 8, False, levels=lv)
     return dev, cpu, vs, qs, lv
 
 
@@ -357,15 +367,51 @@ def test_search_on_a_device_built_graph_is_still_exact(gpu_built):
     assert_search_equal(dev.search_batch(qs, 10, 64), orc.search_batch(qs, 10, 64, nthreads=8), "device-built")
 
 
-def test_device_build_extends_an_existing_index(gpu_built):
-    _, _, vs, qs, lv = gpu_built
+@pytest.mark.parametrize("mode", [1, 2])
+def test_device_build_extends_an_existing_index(build_inputs, mode):
+    _, vs, qs, lv = build_inputs
     idx = H.HNSW.new(16, 32, 100).insert_bulk(vs[:5000], 8, False, levels=lv[:5000])
-    idx.set_option("gpu_build", 1)
+    idx.set_option("gpu_build", mode)
     # a later point above the current top layer would become an entry point that is never connected
     # (the reference's own TODO, hnsw/src/template.rs:283-290): keep the levels below it
     lv2 = np.minimum(lv[5000:12000], lv[:5000].max())
-    idx.insert_bulk(vs[5000:12000], 8, False, levels=lv2)  # routed to the device build
+    # host connect on one thread: racing threads may push a row of the tiny top layer past the 1.1 x
+    # slack of assert_param_compliance, exactly like the reference's own multi-threaded build
+    idx.insert_bulk(vs[5000:12000], 1 if mode == 1 else 8, False, levels=lv2)  # routed to the device build
     assert idx.len() == 12000 and idx.assert_param_compliance()
     truth, _ = idx.brute_force(qs[:64], 10)
     ids, _, _, _ = idx.search_batch(qs[:64], 10, 64)
     assert sum(len(set(a) & set(b)) for a, b in zip(ids.tolist(), truth.tolist())) / 640 > 0.97
+
+
+@pytest.mark.parametrize("kind,m,d", [(H.VEC_F32, 8, 33), (H.VEC_QUANT8, 24, 64), (H.VEC_QUANT8, 5, 100)])
+def test_device_connect_other_shapes(kind, m, d):
+    """device connect on other row strides (m = 5 -> 16 slots, 24 -> 64 slots) and the f32 kind"""
+    n = 12000
+    vs = H.synth_rows(0, 0xC0FFEE + m, 0, n, d)
+    qs = H.synth_rows(0, 0xBEEF + m, 0, 128, d)
+    lv = O.draw_levels(n, m, 9)
+    idx = H.HNSW.new(m, 48, d, kind)
+    idx.set_option("gpu_build", 2)
+    idx.insert_bulk_device(vs, 8, False, levels=lv)
+    assert idx.len() == n
+    # with caps as small as m = 5 one kept-last-edge already exceeds the 1.1 x slack of
+    # assert_param_compliance (the CPU build of the same data does too): bound the degrees directly
+    assert m < 8 or idx.assert_param_compliance()
+    for layer in idx.iter_layers():
+        ids, offs, nbrs = layer.csr()
+        deg = np.diff(offs)
+        assert deg.max() <= (2 * m if layer.level == 0 else m) + 2
+        assert len(ids) == 1 or deg.min() >= 1
+        adj = {int(i): set(int(x) for x in nbrs[int(offs[k]):int(offs[k + 1])]) for k, i in enumerate(ids)}
+        for i in list(adj)[::53]:
+            assert i not in adj[i]
+            for nb in adj[i]:
+                assert i in adj[nb], "edge %d-%d is one-way on layer %d" % (i, nb, layer.level)
+    truth, _ = idx.brute_force(qs, 10)
+    ids, _, _, _ = idx.search_batch(qs, 10, 96)
+    rec = sum(len(set(a) & set(b)) for a, b in zip(ids.tolist(), truth.tolist())) / (len(qs) * 10)
+    assert rec > 0.95, rec
+    # and the search on it is still the reference's search
+    orc = oracle_from_product(idx, vs, lv)
+    assert_search_equal(idx.search_batch(qs, 10, 40), orc.search_batch(qs, 10, 40, nthreads=8), "device-connect")
