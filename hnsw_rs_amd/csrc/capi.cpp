@@ -424,8 +424,8 @@ int gpu_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_th
 // longer than that (the reference's transient overflow) is pruned here the way the next
 // prune_connections would: nearest `cap` by (dist, id), reverse edges removed.  Where the dropped
 // edge is the other node's last one it stays on that side (graph.rs:85-94); the pruned side gets it
-// back after the build (`restore`: {x, node, layer, 0}), exactly like a refusal of hx_remove_kernel.
-void clamp_rows_to_cap(hx::HostIndex &host, std::vector<uint4> *restore) {
+// back after the build (`restore`: hx_edge_key(layer, x, node)), exactly like a refusal of hx_remove_kernel.
+void clamp_rows_to_cap(hx::HostIndex &host, std::vector<uint64_t> *restore) {
     using hx::NodeID;
     for (uint32_t l = 0; l < host.nb_layers(); l++) {
         const size_t cap = (size_t)host.layer_m(l);
@@ -443,7 +443,7 @@ void clamp_rows_to_cap(hx::HostIndex &host, std::vector<uint4> *restore) {
             for (size_t i = cap; i < ds.size(); i++) {
                 std::vector<NodeID> &back = host.row(l, ds[i].id);
                 if (back.size() == 1 && back[0] == id)
-                    restore->push_back(make_uint4(ds[i].id, id, l, 0));
+                    restore->push_back(hx::hx_edge_key(l, ds[i].id, id));
                 else
                     back.erase(std::remove(back.begin(), back.end(), id), back.end());
             }
@@ -452,12 +452,6 @@ void clamp_rows_to_cap(hx::HostIndex &host, std::vector<uint4> *restore) {
         }
     }
 }
-
-struct ReqRec {
-    uint64_t key;  // layer << 32 | target row's node
-    uint32_t src;
-    uint32_t dbits;
-};
 
 int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads, int verbose,
                          const uint8_t *levels) {
@@ -468,6 +462,8 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         set_error("on-device build supports m <= 32 and ef_construction <= 512");
         return HNSW_ERR_ARG;
     }
+    if (host.len() + n >= (1ull << hx::HX_EDGE_ID_BITS))  // edge records carry 30-bit ids
+        return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels);
     const uint64_t n_before = host.len();
     std::vector<NodeID> ids;
     int rc = host.store_points(rows, n, levels, &ids);
@@ -481,22 +477,25 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
                      [&](NodeID x, NodeID y) { return host.levels[x] > host.levels[y]; });
     const uint64_t SEED = 2048;
     size_t pos = 0;
+    std::unique_ptr<hx::Inserter, void (*)(hx::Inserter *)> ins(hx::new_inserter(host.len()), hx::free_inserter);
     if (n_before < SEED) {
         const size_t take = std::min<size_t>(order.size(), SEED - n_before);
-        std::unique_ptr<hx::Inserter, void (*)(hx::Inserter *)> ins(hx::new_inserter(host.len()),
-                                                                     hx::free_inserter);
         for (size_t i = 0; i < take; i++) {
             rc = host.insert(order[i], *ins);
             if (rc != HNSW_OK) return rc;
         }
         pos = take;
     }
-    if (pos == order.size()) {
+    if (pos == order.size() || host.nb_layers() > 16) {  // edge records carry 4-bit layers
+        for (; pos < order.size(); pos++) {
+            rc = host.insert(order[pos], *ins);
+            if (rc != HNSW_OK) return rc;
+        }
         host.version++;
         return HNSW_OK;
     }
     const auto t_start = std::chrono::steady_clock::now();
-    std::vector<uint4> restore;
+    std::vector<uint64_t> restore;
     clamp_rows_to_cap(host, &restore);
     const int saved_inline = h->dev.inline_rows;
     h->dev.inline_rows = 0;
@@ -510,57 +509,26 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     const uint32_t m = (uint32_t)host.params.m, L = host.nb_layers();
     const uint32_t BMAX = 8192;
     const uint32_t REQ_CAP = BMAX * m * 2;  // a point has 1 + 1/(m-1) layers on average
-    DevBuf dLevels, dIds, dOutIds, dOutD, dStatus, dReq, dCnt, dGrpT, dGrpL, dGrpOff, dSrc, dSrcD, dRem, dRef;
+    const uint32_t REF_CAP = 1u << 20;      // kept-last-edge records of the whole build
+    const size_t temp_bytes = hx::sort_temp_bytes(REQ_CAP);
+    DevBuf dLevels, dIds, dOutIds, dOutD, dStatus, dCnt, dKeyA, dKeyB, dValA, dValB, dTemp, dRef;
     if ((rc = dLevels.alloc(host.len())) || (rc = dIds.alloc(BMAX * 4)) ||
         (rc = dOutIds.alloc((size_t)BMAX * L * m * 4)) || (rc = dOutD.alloc((size_t)BMAX * L * m * 4)) ||
-        (rc = dStatus.alloc(BMAX * 4)) || (rc = dReq.alloc((size_t)REQ_CAP * 16)) || (rc = dCnt.alloc(64)) ||
-        (rc = dGrpT.alloc((size_t)REQ_CAP * 4)) || (rc = dGrpL.alloc((size_t)REQ_CAP * 4)) ||
-        (rc = dGrpOff.alloc((size_t)(REQ_CAP + 1) * 4)) || (rc = dSrc.alloc((size_t)REQ_CAP * 4)) ||
-        (rc = dSrcD.alloc((size_t)REQ_CAP * 4)) || (rc = dRem.alloc((size_t)REQ_CAP * 16)) ||
-        (rc = dRef.alloc((size_t)REQ_CAP * 16)))
+        (rc = dStatus.alloc(BMAX * 4)) || (rc = dCnt.alloc(64)) || (rc = dKeyA.alloc((size_t)REQ_CAP * 8)) ||
+        (rc = dKeyB.alloc((size_t)REQ_CAP * 8)) || (rc = dValA.alloc((size_t)REQ_CAP * 4)) ||
+        (rc = dValB.alloc((size_t)REQ_CAP * 4)) || (rc = dTemp.alloc(temp_bytes)) ||
+        (rc = dRef.alloc((size_t)REF_CAP * 8)))
         return rc;
     HIP_TRY(hipMemcpy(dLevels.p, host.levels.data(), host.len(), hipMemcpyHostToDevice));
-    // counters: [0] requests, [1] removals, [2] refusals (accumulates over the build), [3] status
+    // counters: [0] requests, [1] removals, [2] refusals (accumulate over the build), [3] status
     uint32_t *cnt = dCnt.as<uint32_t>();
     HIP_TRY(hipMemset(dCnt.p, 0, 64));
     std::vector<int32_t> o_st(BMAX);
-    std::vector<uint4> recs(REQ_CAP);
-    std::vector<ReqRec> sorted;
-    std::vector<uint32_t> g_t, g_l, g_off, g_src, g_d;
     std::vector<NodeID> failed;
     uint64_t connected = n_before + pos;
-    double t_ins = 0, t_host = 0, t_conn = 0;
+    double t_ins = 0, t_conn = 0;
     size_t n_batches = 0, n_req = 0, n_rem = 0;
-
-    // groups the records by key and ships them; returns the number of groups
-    auto ship_groups = [&](size_t count, bool with_dists) -> long {
-        std::sort(sorted.begin(), sorted.begin() + count,
-                  [](const ReqRec &x, const ReqRec &y) { return x.key < y.key || (x.key == y.key && x.src < y.src); });
-        g_t.clear(); g_l.clear(); g_off.clear();
-        g_src.resize(count);
-        g_d.resize(count);
-        for (size_t i = 0; i < count; i++) {
-            if (i == 0 || sorted[i].key != sorted[i - 1].key) {
-                g_t.push_back((uint32_t)sorted[i].key);
-                g_l.push_back((uint32_t)(sorted[i].key >> 32));
-                g_off.push_back((uint32_t)i);
-            }
-            g_src[i] = sorted[i].src;
-            g_d[i] = sorted[i].dbits;
-        }
-        g_off.push_back((uint32_t)count);
-        const size_t G = g_t.size();
-        if (G == 0) return 0;
-        if (hipMemcpy(dGrpT.p, g_t.data(), G * 4, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(dGrpL.p, g_l.data(), G * 4, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(dGrpOff.p, g_off.data(), (G + 1) * 4, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(dSrc.p, g_src.data(), count * 4, hipMemcpyHostToDevice) != hipSuccess ||
-            (with_dists && hipMemcpy(dSrcD.p, g_d.data(), count * 4, hipMemcpyHostToDevice) != hipSuccess)) {
-            set_error("on-device build: copy of the request groups failed");
-            return -1;
-        }
-        return (long)G;
-    };
+    uint32_t counts[4];
 
     while (pos < order.size()) {
         const size_t B = std::min<size_t>(order.size() - pos,
@@ -569,6 +537,7 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         auto t0 = std::chrono::steady_clock::now();
         HIP_TRY(hipMemcpy(dIds.p, batch, B * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemset(dCnt.p, 0, 8));  // requests, removals
+        // ---- phase 1: searches + heuristic, own rows, requests ----
         hx::InsertArgs a{};
         a.point_ids = dIds.as<uint32_t>();
         a.levels = dLevels.as<uint8_t>();
@@ -580,112 +549,74 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         a.out_status = dStatus.as<int32_t>();
         a.adj0_mut = h->dev.adj0_mut();
         a.adj_up_mut = h->dev.adj_up_mut();
-        a.req = dReq.as<uint4>();
+        a.req_keys = dKeyA.as<uint64_t>();
+        a.req_vals = dValA.as<uint32_t>();
         a.req_count = cnt + 0;
         a.req_cap = REQ_CAP;
         rc = hx::launch_insert(v, a, (uint32_t)B, nullptr);
         if (rc != HNSW_OK) return rc;
-        uint32_t counts[4];
         HIP_TRY(hipMemcpy(counts, dCnt.p, 16, hipMemcpyDeviceToHost));  // synchronises
         HIP_TRY(hipMemcpy(o_st.data(), dStatus.p, B * 4, hipMemcpyDeviceToHost));
-        size_t nreq = std::min<uint32_t>(counts[0], REQ_CAP);
-        HIP_TRY(hipMemcpy(recs.data(), dReq.p, nreq * 16, hipMemcpyDeviceToHost));
-        auto t1 = std::chrono::steady_clock::now();
-
-        // requests of points that failed (visited-table overflow, request buffer full) are dropped:
-        // those points take the CPU path after the build
-        bool any_failed = false;
         for (size_t i = 0; i < B; i++)
-            if (o_st[i] != HNSW_OK) {
-                failed.push_back(batch[i]);
-                any_failed = true;
-            }
-        std::vector<NodeID> failed_sorted;
-        if (any_failed) {
-            failed_sorted = failed;
-            std::sort(failed_sorted.begin(), failed_sorted.end());
-        }
-        sorted.resize(std::max(sorted.size(), nreq));
-        size_t cnt_ok = 0;
-        for (size_t i = 0; i < nreq; i++) {
-            const uint4 &r = recs[i];
-            if (any_failed && std::binary_search(failed_sorted.begin(), failed_sorted.end(), r.y)) continue;
-            if (r.x >= host.len() || r.y >= host.len() || r.z > host.levels[r.x] || r.z > host.levels[r.y]) {
-                set_error("on-device build: malformed request (target %u, source %u, layer %u) in batch %zu",
-                          r.x, r.y, r.z, n_batches);
-                return HNSW_ERR_NODE_NOT_IN_GRAPH;
-            }
-            sorted[cnt_ok++] = ReqRec{((uint64_t)r.z << 32) | r.x, r.y, r.w};
-        }
-        long G = ship_groups(cnt_ok, true);
-        if (G < 0) return HNSW_ERR_HIP;
-        n_req += cnt_ok;
-        auto t2 = std::chrono::steady_clock::now();
+            if (o_st[i] != HNSW_OK) failed.push_back(batch[i]);  // filed nothing; CPU path after the build
+        const uint32_t nreq = std::min<uint32_t>(counts[0], REQ_CAP);
+        auto t1 = std::chrono::steady_clock::now();
+        // ---- phase 2: group by target row (radix sort), append / prune ----
+        rc = hx::sort_edge_pairs(dTemp.p, temp_bytes, dKeyA.as<uint64_t>(), dKeyB.as<uint64_t>(),
+                                 dValA.as<uint32_t>(), dValB.as<uint32_t>(), nreq, L, nullptr);
+        if (rc != HNSW_OK) return rc;
         hx::ConnectArgs ca{};
-        ca.grp_target = dGrpT.as<uint32_t>();
-        ca.grp_layer = dGrpL.as<uint32_t>();
-        ca.grp_off = dGrpOff.as<uint32_t>();
-        ca.src_ids = dSrc.as<uint32_t>();
-        ca.src_dists = dSrcD.as<float>();
+        ca.keys = dKeyB.as<uint64_t>();
+        ca.vals = dValB.as<uint32_t>();
+        ca.count = nreq;
         ca.m = m;
         ca.adj0_mut = h->dev.adj0_mut();
         ca.adj_up_mut = h->dev.adj_up_mut();
-        ca.out = dRem.as<uint4>();
+        ca.out_keys = dKeyA.as<uint64_t>();  // the unsorted requests are dead by now
         ca.out_count = cnt + 1;
         ca.out_cap = REQ_CAP;
         ca.status = reinterpret_cast<int32_t *>(cnt + 3);
-        rc = hx::launch_connect(v, ca, (uint32_t)G, nullptr);
+        rc = hx::launch_connect(v, ca, nullptr);
         if (rc != HNSW_OK) return rc;
         HIP_TRY(hipMemcpy(counts, dCnt.p, 16, hipMemcpyDeviceToHost));
         if (counts[3] != 0) {
             set_error("on-device build: connect kernel reported status %d in batch %zu", (int)counts[3], n_batches);
             return (int)counts[3];
         }
-        const size_t nrem = counts[1];
-        auto t3 = std::chrono::steady_clock::now();
-        if (nrem) {
-            HIP_TRY(hipMemcpy(recs.data(), dRem.p, nrem * 16, hipMemcpyDeviceToHost));
-            sorted.resize(std::max(sorted.size(), nrem));
-            for (size_t i = 0; i < nrem; i++) {
-                if (recs[i].x >= host.len() || recs[i].z > host.levels[recs[i].x]) {
-                    set_error("on-device build: malformed removal (row %u, drops %u, layer %u) in batch %zu",
-                              recs[i].x, recs[i].y, recs[i].z, n_batches);
-                    return HNSW_ERR_NODE_NOT_IN_GRAPH;
-                }
-                sorted[i] = ReqRec{((uint64_t)recs[i].z << 32) | recs[i].x, recs[i].y, 0};
-            }
-            G = ship_groups(nrem, false);
-            if (G < 0) return HNSW_ERR_HIP;
-            auto t4 = std::chrono::steady_clock::now();
-            t_host += std::chrono::duration<double>(t4 - t3).count();
-            ca.out = dRef.as<uint4>();
-            ca.out_count = cnt + 2;
-            rc = hx::launch_remove(v, ca, (uint32_t)G, nullptr);
-            if (rc != HNSW_OK) return rc;
-            HIP_TRY(hipDeviceSynchronize());
-            t_conn += std::chrono::duration<double>(std::chrono::steady_clock::now() - t4).count();
-            n_rem += nrem;
-        }
+        // ---- phase 3: group the removals by row, drop the reverse edges ----
+        const uint32_t nrem = counts[1];
+        rc = hx::sort_edge_keys(dTemp.p, temp_bytes, dKeyA.as<uint64_t>(), dKeyB.as<uint64_t>(), nrem, L, nullptr);
+        if (rc != HNSW_OK) return rc;
+        ca.keys = dKeyB.as<uint64_t>();
+        ca.vals = nullptr;
+        ca.count = nrem;
+        ca.out_keys = dRef.as<uint64_t>();
+        ca.out_count = cnt + 2;
+        ca.out_cap = REF_CAP;
+        rc = hx::launch_remove(v, ca, nullptr);
+        if (rc != HNSW_OK) return rc;
+        if (verbose) HIP_TRY(hipDeviceSynchronize());  // only to attribute the time
+        auto t2 = std::chrono::steady_clock::now();
         t_ins += std::chrono::duration<double>(t1 - t0).count();
-        t_host += std::chrono::duration<double>(t2 - t1).count();
-        t_conn += std::chrono::duration<double>(t3 - t2).count();
+        t_conn += std::chrono::duration<double>(t2 - t1).count();
+        n_req += nreq;
+        n_rem += nrem;
         pos += B;
         connected += B;
         n_batches++;
-        if (verbose && (n_batches % 16 == 0 || pos == order.size()))
+        if (verbose && (n_batches % 64 == 0 || pos == order.size()))
             fprintf(stderr, "\rBuilding HNSW index on the GPU %zu/%zu", pos, order.size());
     }
 
     // ---- the host graph from the device arrays ----
     const auto t_sync0 = std::chrono::steady_clock::now();
-    uint32_t counts[4];
     HIP_TRY(hipMemcpy(counts, dCnt.p, 16, hipMemcpyDeviceToHost));
-    if (counts[3] != 0 || counts[2] > REQ_CAP) {
-        set_error("on-device build: refusal buffer overflow");
+    if (counts[3] != 0 || counts[2] > REF_CAP) {
+        set_error("on-device build: status %d, %u kept-last-edge records", (int)counts[3], counts[2]);
         return HNSW_ERR_OVERFLOW;
     }
-    std::vector<uint4> refusals(counts[2]);
-    if (counts[2]) HIP_TRY(hipMemcpy(refusals.data(), dRef.p, (size_t)counts[2] * 16, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> refusals(counts[2]);
+    if (counts[2]) HIP_TRY(hipMemcpy(refusals.data(), dRef.p, (size_t)counts[2] * 8, hipMemcpyDeviceToHost));
     {
         std::vector<uint32_t> buf;
         for (int pass = 0; pass < 2; pass++) {
@@ -717,20 +648,19 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     }
     // an edge x -> nb that stayed because it was x's last one: restore nb -> x (graph.rs:85-94 keeps both)
     refusals.insert(refusals.end(), restore.begin(), restore.end());
-    for (const uint4 &r : refusals) {
-        std::vector<NodeID> &row = host.row(r.z, r.y);
-        const std::vector<NodeID> &back = host.row(r.z, r.x);
-        if (std::find(back.begin(), back.end(), r.y) != back.end() &&
-            std::find(row.begin(), row.end(), r.x) == row.end())
-            row.push_back(r.x);
+    const uint64_t id_mask = (1ull << hx::HX_EDGE_ID_BITS) - 1;
+    for (uint64_t key : refusals) {
+        const uint32_t layer = (uint32_t)(key >> (2 * hx::HX_EDGE_ID_BITS));
+        const NodeID x = (NodeID)((key >> hx::HX_EDGE_ID_BITS) & id_mask), nb = (NodeID)(key & id_mask);
+        std::vector<NodeID> &row = host.row(layer, nb);
+        const std::vector<NodeID> &back = host.row(layer, x);
+        if (std::find(back.begin(), back.end(), nb) != back.end() &&
+            std::find(row.begin(), row.end(), x) == row.end())
+            row.push_back(x);
     }
-    // points the kernel could not serve: their partial rows are cleared, then the CPU path inserts them
+    // points the kernel could not serve take the CPU path
     if (!failed.empty()) {
         std::sort(failed.begin(), failed.end());
-        for (NodeID p : failed)
-            for (uint32_t l = 0; l <= host.levels[p]; l++) host.row(l, p).clear();
-        std::unique_ptr<hx::Inserter, void (*)(hx::Inserter *)> ins(hx::new_inserter(host.len()),
-                                                                     hx::free_inserter);
         for (NodeID p : failed) {
             rc = host.insert(p, *ins);
             if (rc != HNSW_OK) return rc;
@@ -740,10 +670,10 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         const double tot = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
         const double t_sync = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_sync0).count();
         fprintf(stderr,
-                "\non-device build (device connect): %zu batches in %.2f s (insert kernel %.2f s, host grouping "
-                "%.2f s, connect/remove kernels %.2f s, graph read-back %.2f s); %zu requests, %zu removals, "
-                "%u kept-last-edge, %zu points took the CPU path\n",
-                n_batches, tot, t_ins, t_host, t_conn, t_sync, n_req, n_rem, counts[2], failed.size());
+                "\non-device build (device connect): %zu batches in %.2f s (insert kernel %.2f s, sort + connect + "
+                "remove %.2f s, graph read-back %.2f s); %zu requests, %zu removals, %u kept-last-edge, %zu points "
+                "took the CPU path\n",
+                n_batches, tot, t_ins, t_conn, t_sync, n_req, n_rem, counts[2], failed.size());
     }
     host.version++;
     return HNSW_OK;

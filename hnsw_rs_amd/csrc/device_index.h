@@ -84,26 +84,43 @@ struct InsertArgs {
     uint32_t *out_ids;          // [n][max_layers][m], padded with 0xFFFFFFFF
     float *out_dists;           // [n][max_layers][m]
     int32_t *out_status;        // [n]
-    // full on-device connect (optional, all null otherwise): the kernel writes the point's own rows
-    // and appends one reverse-edge request per selected neighbour
+    // full on-device connect (optional, all null otherwise): a point whose searches all succeeded
+    // writes its own rows and appends one reverse-edge request per selected neighbour
     uint32_t *adj0_mut, *adj_up_mut;
-    uint4 *req;                 // {target, source, layer, dist bits}
+    uint64_t *req_keys;         // hx_edge_key(layer, target, source)
+    uint32_t *req_vals;         // bits of d(source, target)
     uint32_t *req_count;
     uint32_t req_cap;
 };
 
-// phase 2 / 3 of the on-device connect: groups of requests that share a (layer, target) row
+// An edge record of the on-device connect, made to be radix-sorted: records of one adjacency row
+// (layer, row node) become adjacent and ordered by the other node.  Needs ids < 2^30, layers < 16.
+static constexpr uint32_t HX_EDGE_ID_BITS = 30;
+static inline __host__ __device__ uint64_t hx_edge_key(uint32_t layer, uint32_t row_node, uint32_t other) {
+    return ((uint64_t)layer << (2 * HX_EDGE_ID_BITS)) | ((uint64_t)row_node << HX_EDGE_ID_BITS) | other;
+}
+
+// phase 2 / 3 of the on-device connect: sorted edge records, one wave per record; the wave of the
+// first record of a row handles the row, the others exit
 struct ConnectArgs {
-    const uint32_t *grp_target, *grp_layer, *grp_off;  // n_groups (+1 for off)
-    const uint32_t *src_ids;                           // sources (phase 2) / neighbours to drop (phase 3)
-    const float *src_dists;                            // phase 2 only
+    const uint64_t *keys;   // sorted
+    const uint32_t *vals;   // phase 2: distance bits in the same order; phase 3: unused
+    uint32_t count;
     uint32_t m;
     uint32_t *adj0_mut, *adj_up_mut;
-    uint4 *out;                                        // phase 2: removals {x, n, layer, 0}; phase 3: refusals
+    uint64_t *out_keys;     // phase 2: removals hx_edge_key(layer, x, n); phase 3: refusals (same form)
     uint32_t *out_count;
     uint32_t out_cap;
-    int32_t *status;                                   // single word, set on overflow of `out`
+    int32_t *status;        // single word: set when `out` is full or a record is malformed
 };
+
+// device radix sorts of the edge records (build_sort.hip, rocPRIM)
+size_t sort_temp_bytes(uint32_t max_n);
+int sort_edge_pairs(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
+                    const uint32_t *vals_in, uint32_t *vals_out, uint32_t n, uint32_t nb_layers,
+                    hipStream_t stream);
+int sort_edge_keys(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out, uint32_t n,
+                   uint32_t nb_layers, hipStream_t stream);
 
 class DeviceIndex {
   public:
@@ -142,8 +159,8 @@ uint32_t default_slots_log2(uint32_t ef);
 uint32_t max_slots_log2(uint32_t ef);
 
 int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipStream_t stream);
-int launch_connect(const DevView &v, const ConnectArgs &a, uint32_t n_groups, hipStream_t stream);
-int launch_remove(const DevView &v, const ConnectArgs &a, uint32_t n_groups, hipStream_t stream);
+int launch_connect(const DevView &v, const ConnectArgs &a, hipStream_t stream);
+int launch_remove(const DevView &v, const ConnectArgs &a, hipStream_t stream);
 int launch_scatter_rows(uint32_t *dst, uint32_t S, const uint32_t *d_row_index, const uint32_t *d_data,
                         uint32_t n, hipStream_t stream);
 

@@ -1794,20 +1794,6 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
             o_ids[(size_t)layer * m + lane] = (uint32_t)mine;
             o_d[(size_t)layer * m + lane] = __builtin_bit_cast(float, (uint32_t)(mine >> 32));
         }
-        if (a.req != nullptr) {
-            // on-device connect: this point's own row (nobody can reach p yet) and one reverse-edge
-            // request per selected neighbour
-            const uint32_t S = layer == 0 ? v.S0 : v.S1;
-            uint32_t *row = layer == 0 ? a.adj0_mut + (size_t)p * S
-                                       : a.adj_up_mut + ((size_t)v.upper_base[p] + layer - 1) * S;
-            for (uint32_t k = lane; k < S; k += 64) row[k] = k < ns ? (uint32_t)selk[k] : HX_EMPTY_SLOT;
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(a.req_count, ns);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if ((uint32_t)lane < ns && base + lane < a.req_cap)
-                a.req[base + lane] = make_uint4((uint32_t)mine, p, (uint32_t)layer, (uint32_t)(mine >> 32));
-            if (base + ns > a.req_cap) status = HNSW_ERR_OVERFLOW;
-        }
 #pragma unroll
         for (int r = 0; r < R; r++) wl.L[r] = KEY_INVALID;
         wl.n_cur = 0;
@@ -1818,6 +1804,37 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
         int32_t st = status;
         for (int o = 32; o > 0; o >>= 1) st = min(st, __shfl_xor(st, o));
         status = st;
+    }
+    if (a.req_keys != nullptr && status == HNSW_OK) {
+        // on-device connect: only a point whose every layer succeeded writes its own rows (nobody can
+        // reach p yet) and files one reverse-edge request per selected neighbour
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        uint32_t total = 0;
+        for (uint32_t l = 0; l <= level; l++) {
+            const uint32_t id = (uint32_t)lane < m ? o_ids[(size_t)l * m + lane] : HX_EMPTY_SLOT;
+            total += (uint32_t)__popcll(__ballot(id != HX_EMPTY_SLOT));
+        }
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.req_count, total);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base + total > a.req_cap) {
+            status = HNSW_ERR_OVERFLOW;  // nothing written: the point takes the CPU path
+        } else {
+            for (uint32_t l = 0; l <= level; l++) {
+                const uint32_t S = l == 0 ? v.S0 : v.S1;
+                uint32_t *row = l == 0 ? a.adj0_mut + (size_t)p * S
+                                       : a.adj_up_mut + ((size_t)v.upper_base[p] + l - 1) * S;
+                const uint32_t id = (uint32_t)lane < m ? o_ids[(size_t)l * m + lane] : HX_EMPTY_SLOT;
+                if ((uint32_t)lane < S) row[lane] = id;
+                const u64 vm = __ballot(id != HX_EMPTY_SLOT);  // a prefix of the lanes
+                if (id != HX_EMPTY_SLOT) {
+                    a.req_keys[base + lane] = hx_edge_key(l, id, p);
+                    a.req_vals[base + lane] = __builtin_bit_cast(uint32_t, o_d[(size_t)l * m + lane]);
+                }
+                base += (uint32_t)__popcll(vm);
+            }
+        }
     }
     if (lane == 0) a.out_status[b] = status;
 }
@@ -1871,14 +1888,34 @@ int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipSt
 }
 
 // ---------------------------------------------------------------------------------------------
-// On-device connect, phase 2: one wave per (layer, target) row that received reverse-edge requests
-// in this batch.  make_connections adds the sources (template.rs:196-207); a row that would exceed
-// the layer's cap is pruned to its `cap` nearest by (dist, id) (prune_connections / select_simple,
-// template.rs:209-238,614-621) -- distances of the existing neighbours are evaluated here, the
-// sources bring d(p, n) = d(n, p).  Every dropped neighbour x (and every source that did not make
-// it) is reported so that phase 3 removes the reverse edge (remove_edge is symmetric,
-// graph.rs:72-83).  Rows are owned by exactly one wave per phase: no locks, no atomics on rows.
+// On-device connect.  Edge records hx_edge_key(layer, row node, other node) arrive radix-sorted, so
+// the records of one adjacency row are adjacent; one wave is launched per record, the wave of a
+// row's first record owns the row for the phase and the others exit at once.  Rows are owned by
+// exactly one wave per phase: no locks, no atomics on rows, deterministic for a given batch.
+//
+// Phase 2 (hx_connect_kernel): make_connections adds the sources to the row (template.rs:196-207); a
+// row that would exceed the layer's cap is pruned to its `cap` nearest by (dist, id)
+// (prune_connections / select_simple, template.rs:209-238,614-621) -- distances of the existing
+// neighbours are evaluated here, the sources bring d(p, n) = d(n, p).  Every dropped neighbour x (and
+// every source that did not make it) is reported so that phase 3 removes the reverse edge
+// (remove_edge is symmetric, graph.rs:72-83).
 // ---------------------------------------------------------------------------------------------
+static constexpr uint64_t HX_EDGE_ID_MASK = (1ull << HX_EDGE_ID_BITS) - 1;
+
+// number of records of the row that starts at record i (0 if i is not the first of its row)
+__device__ __forceinline__ uint32_t edge_group_size(const uint64_t *keys, uint32_t count, uint32_t i, int lane) {
+    const uint64_t prefix = keys[i] >> HX_EDGE_ID_BITS;
+    if (i > 0 && (keys[i - 1] >> HX_EDGE_ID_BITS) == prefix) return 0;
+    uint32_t k = 1;
+    for (;;) {
+        const uint32_t j = i + k + lane;
+        const bool same = j < count && (keys[j] >> HX_EDGE_ID_BITS) == prefix;
+        const u64 diff = ~__ballot(same);
+        if (diff) return k + (uint32_t)(__ffsll((long long)diff) - 1);
+        k += 64;
+    }
+}
+
 template <int KIND>
 __global__ void __launch_bounds__(64)
 hx_connect_kernel(const DevView v, const ConnectArgs a) {
@@ -1887,13 +1924,17 @@ hx_connect_kernel(const DevView v, const ConnectArgs a) {
     u64 *ekeys = perm + 64;                           // [64] keys of the existing neighbours
     float *yq = reinterpret_cast<float *>(ekeys + 64);
     const int lane = threadIdx.x;
-    const uint32_t g = blockIdx.x;
-    const uint32_t n = a.grp_target[g], layer = a.grp_layer[g];
-    const uint32_t lo = a.grp_off[g], k = a.grp_off[g + 1] - lo;
+    const uint32_t lo = blockIdx.x;
+    if (lo >= a.count) return;
+    const uint32_t k = edge_group_size(a.keys, a.count, lo, lane);
+    if (k == 0) return;
+    const uint64_t head = a.keys[lo];
+    const uint32_t n = (uint32_t)((head >> HX_EDGE_ID_BITS) & HX_EDGE_ID_MASK);
+    const uint32_t layer = (uint32_t)(head >> (2 * HX_EDGE_ID_BITS));
     const uint32_t S = layer == 0 ? v.S0 : v.S1;
     const uint32_t cap = layer == 0 ? 2 * a.m : a.m;
     if (n >= v.n_points || layer >= v.nb_layers || (layer > 0 && v.upper_base[n] == HX_EMPTY_SLOT)) {
-        *a.status = HNSW_ERR_NODE_NOT_IN_GRAPH;  // a malformed group: never touch memory for it
+        *a.status = HNSW_ERR_NODE_NOT_IN_GRAPH;  // a malformed record: never touch memory for it
         return;
     }
     uint32_t *row = layer == 0 ? a.adj0_mut + (size_t)n * S
@@ -1909,11 +1950,9 @@ hx_connect_kernel(const DevView v, const ConnectArgs a) {
     const u64 hm = __ballot(has);
     const uint32_t deg = (uint32_t)__popcll(hm);
     if (deg + k <= cap && deg + k <= S) {  // room for every source: append
-        // compact the existing ids to the front, then the sources
         const uint32_t pos = (uint32_t)__popcll(hm & ((1ull << lane) - 1));
-        wave_fence();
-        if (has) row[pos] = cur;
-        for (uint32_t j = lane; j < k; j += 64) row[deg + j] = a.src_ids[lo + j];
+        if (has) row[pos] = cur;  // all reads of the row happened above
+        for (uint32_t j = lane; j < k; j += 64) row[deg + j] = (uint32_t)(a.keys[lo + j] & HX_EDGE_ID_MASK);
         for (uint32_t j = deg + k + lane; j < S; j += 64) row[j] = HX_EMPTY_SLOT;
         return;
     }
@@ -1938,14 +1977,11 @@ hx_connect_kernel(const DevView v, const ConnectArgs a) {
         }
         wl.merge(key, cap, perm, lane);
     }
-    for (uint32_t j0 = 0; j0 < k; j0 += 64) {  // the sources
-        const uint32_t j = j0 + lane;
-        u64 key = KEY_INVALID;
-        if (j < k) key = ((u64)__builtin_bit_cast(uint32_t, a.src_dists[lo + j]) << 32) | a.src_ids[lo + j];
-        wl.merge(key, cap, perm, lane);
-    }
+    auto source_key = [&](uint32_t j) -> u64 {
+        return j < k ? ((u64)a.vals[lo + j] << 32) | (uint32_t)(a.keys[lo + j] & HX_EDGE_ID_MASK) : KEY_INVALID;
+    };
+    for (uint32_t j0 = 0; j0 < k; j0 += 64) wl.merge(source_key(j0 + lane), cap, perm, lane);
     wave_fence();
-    // the new row
     if ((uint32_t)lane < S) row[lane] = (uint32_t)lane < wl.n_cur ? (uint32_t)wl.L[0] : HX_EMPTY_SLOT;
     // report what fell out: key > the last kept key (keys are distinct)
     const u64 lastk = wl.n_cur >= cap ? wl.last_key : KEY_INVALID;
@@ -1959,31 +1995,30 @@ hx_connect_kernel(const DevView v, const ConnectArgs a) {
         const uint32_t at = base + (uint32_t)__popcll(dm & ((1ull << lane) - 1));
         if (drop) {
             if (at < a.out_cap)
-                a.out[at] = make_uint4((uint32_t)key, n, layer, 0);
+                a.out_keys[at] = hx_edge_key(layer, (uint32_t)key, n);
             else
                 *a.status = HNSW_ERR_OVERFLOW;
         }
     };
     emit(ekeys[lane]);
-    for (uint32_t j0 = 0; j0 < k; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        u64 key = KEY_INVALID;
-        if (j < k) key = ((u64)__builtin_bit_cast(uint32_t, a.src_dists[lo + j]) << 32) | a.src_ids[lo + j];
-        emit(key);
-    }
+    for (uint32_t j0 = 0; j0 < k; j0 += 64) emit(source_key(j0 + lane));
 }
 
 // ---------------------------------------------------------------------------------------------
-// On-device connect, phase 3: one wave per (layer, x) row that must drop neighbours because they
-// dropped x in phase 2.  An edge to x's LAST neighbour is kept (isolate_node, graph.rs:85-94): such
-// a refusal is reported and the host restores the reverse direction after the build.
+// Phase 3 (hx_remove_kernel): the row of x drops the neighbours that dropped x in phase 2.  An edge
+// to x's LAST neighbour is kept (isolate_node, graph.rs:85-94): such a refusal is reported and the
+// host restores the reverse direction after the build.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
 hx_remove_kernel(const DevView v, const ConnectArgs a) {
     const int lane = threadIdx.x;
-    const uint32_t g = blockIdx.x;
-    const uint32_t x = a.grp_target[g], layer = a.grp_layer[g];
-    const uint32_t lo = a.grp_off[g], k = a.grp_off[g + 1] - lo;
+    const uint32_t lo = blockIdx.x;
+    if (lo >= a.count) return;
+    const uint32_t k = edge_group_size(a.keys, a.count, lo, lane);
+    if (k == 0) return;
+    const uint64_t head = a.keys[lo];
+    const uint32_t x = (uint32_t)((head >> HX_EDGE_ID_BITS) & HX_EDGE_ID_MASK);
+    const uint32_t layer = (uint32_t)(head >> (2 * HX_EDGE_ID_BITS));
     const uint32_t S = layer == 0 ? v.S0 : v.S1;
     if (x >= v.n_points || layer >= v.nb_layers || (layer > 0 && v.upper_base[x] == HX_EMPTY_SLOT)) {
         *a.status = HNSW_ERR_NODE_NOT_IN_GRAPH;
@@ -1994,14 +2029,14 @@ hx_remove_kernel(const DevView v, const ConnectArgs a) {
     uint32_t cur = (uint32_t)lane < S ? row[lane] : HX_EMPTY_SLOT;
     uint32_t deg = (uint32_t)__popcll(__ballot(cur != HX_EMPTY_SLOT));
     for (uint32_t j = 0; j < k; j++) {
-        const uint32_t nb = a.src_ids[lo + j];
+        const uint32_t nb = (uint32_t)(a.keys[lo + j] & HX_EDGE_ID_MASK);
         const u64 hit = __ballot(cur == nb);
         if (hit == 0) continue;
         if (deg == 1) {  // the last edge stays
             if (lane == 0) {
                 const uint32_t at = atomicAdd(a.out_count, 1u);
                 if (at < a.out_cap)
-                    a.out[at] = make_uint4(x, nb, layer, 0);
+                    a.out_keys[at] = hx_edge_key(layer, x, nb);
                 else
                     *a.status = HNSW_ERR_OVERFLOW;
             }
@@ -2018,15 +2053,15 @@ hx_remove_kernel(const DevView v, const ConnectArgs a) {
     if ((uint32_t)lane >= left && (uint32_t)lane < S) row[lane] = HX_EMPTY_SLOT;
 }
 
-int launch_connect(const DevView &v, const ConnectArgs &a, uint32_t n_groups, hipStream_t stream) {
-    if (n_groups == 0) return HNSW_OK;
+int launch_connect(const DevView &v, const ConnectArgs &a, hipStream_t stream) {
+    if (a.count == 0) return HNSW_OK;
     const size_t yq_bytes =
         ((v.kind == HNSW_VEC_QUANT8 ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4) + 15) & ~15ull;
     const size_t lds = 2 * 64 * 8 + yq_bytes;
     if (v.kind == HNSW_VEC_QUANT8)
-        hipLaunchKernelGGL(hx_connect_kernel<HNSW_VEC_QUANT8>, dim3(n_groups), dim3(64), lds, stream, v, a);
+        hipLaunchKernelGGL(hx_connect_kernel<HNSW_VEC_QUANT8>, dim3(a.count), dim3(64), lds, stream, v, a);
     else
-        hipLaunchKernelGGL(hx_connect_kernel<HNSW_VEC_F32>, dim3(n_groups), dim3(64), lds, stream, v, a);
+        hipLaunchKernelGGL(hx_connect_kernel<HNSW_VEC_F32>, dim3(a.count), dim3(64), lds, stream, v, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("connect kernel launch: %s", hipGetErrorString(e));
@@ -2035,9 +2070,9 @@ int launch_connect(const DevView &v, const ConnectArgs &a, uint32_t n_groups, hi
     return HNSW_OK;
 }
 
-int launch_remove(const DevView &v, const ConnectArgs &a, uint32_t n_groups, hipStream_t stream) {
-    if (n_groups == 0) return HNSW_OK;
-    hipLaunchKernelGGL(hx_remove_kernel, dim3(n_groups), dim3(64), 0, stream, v, a);
+int launch_remove(const DevView &v, const ConnectArgs &a, hipStream_t stream) {
+    if (a.count == 0) return HNSW_OK;
+    hipLaunchKernelGGL(hx_remove_kernel, dim3(a.count), dim3(64), 0, stream, v, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("remove kernel launch: %s", hipGetErrorString(e));

@@ -105,14 +105,18 @@ int hnsw_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_t
  * reproducible tests pass levels in. */
 int hnsw_insert_bulk_levels(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads,
                             int verbose, const uint8_t *levels);
-/* insert_bulk with the insertion searches on the GPU (on-device build): per
- * batch one wave per point runs Inserter::build_insertion_results (inserter.rs:40-126: entry point,
- * greedy descent, search_layer(ef_cons) + select_heuristic per layer) against the graph in HBM; the
- * host applies make_connections / prune_connections / make_pruned_connections (template.rs:196-251)
- * on nb_threads threads and the changed adjacency rows are scattered back.  Points of one batch do
- * not see each other (like the racing threads of the reference's multi-threaded insert_bulk), so
- * the graph is judged by recall, not by identity with the sequential build.  Needs m <= 32 and
- * ef_construction <= 512.  hnsw_set_option(h, "gpu_build", 1) routes hnsw_insert_bulk here. */
+/* insert_bulk on the GPU (on-device build), batch-synchronous.  Per batch one
+ * wave per point runs Inserter::build_insertion_results (inserter.rs:40-126: entry point, greedy
+ * descent, search_layer(ef_cons) + select_heuristic per layer) against the graph in HBM and files one
+ * reverse-edge request per selected neighbour; the requests are radix-sorted by target row and one
+ * wave per row applies make_connections / prune_connections (template.rs:196-238: append, or keep
+ * the cap's nearest), a third pass drops the reverse edges of what was pruned (graph.rs:72-94, a
+ * node's last edge stays).  The host graph is read back once at the end.  Points of one batch do not
+ * see each other (like the racing threads of the reference's multi-threaded insert_bulk), so the graph
+ * is judged by recall and invariants, not by identity with the sequential build.  Needs m <= 32 and
+ * ef_construction <= 512; nb_threads is used for the host-side parts (store, seed, read-back).
+ * hnsw_set_option(h, "gpu_build", 2) routes hnsw_insert_bulk here; "gpu_build" = 1 selects the older
+ * hybrid form (GPU searches, connect / prune on nb_threads host threads with the reference's locks). */
 int hnsw_insert_bulk_device(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads,
                             int verbose, const uint8_t *levels);
 /* HNSW::insert_vec(&mut self, &Vec<f32>) -> Result<NodeID, String>, template.rs:165-173 */
@@ -199,7 +203,9 @@ int hnsw_device_bytes(const hnsw_index *h, uint64_t *bytes);
  *                      copy of every neighbour's vector row next to the adjacency slot, so that one
  *                      expansion is one coalesced read; costs 2m x the row bytes of HBM)
  *   "inline_budget_mb" largest inline-rows allocation the auto mode accepts (default 65536)
- *   "gpu_build"        1: hnsw_insert_bulk(_levels) runs the on-device build */
+ *   "gpu_build"        0 (default): hnsw_insert_bulk(_levels) is the CPU build; 2: it runs the on-device
+ *                      build; 1: on-device searches with connect / prune on host threads (also what
+ *                      hnsw_insert_bulk_device does while this is 1) */
 int hnsw_set_option(hnsw_index *h, const char *key, int64_t value);
 
 /* ---- harness helpers (not part of the reference's API) --------------------------------------- */
