@@ -452,6 +452,54 @@ struct QRegs {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Distance of a stored point to the staged row on the build path.  DS > 0: the dimension is a
+// compile-time constant (all row pieces in flight, dead elements vanish), otherwise the runtime
+// loops of dist_any_dim.  QUANT8: valid on the even lane of the pair; F32: per lane.
+// ---------------------------------------------------------------------------------------------
+template <int KIND, int DS>
+__device__ __forceinline__ float dist_build(const DevView &v, uint32_t id, bool active, int h, const float *yq) {
+    if constexpr (DS > 0 && KIND == HNSW_VEC_QUANT8) {
+        constexpr int NQ = 4 * (DS / 8) + DS % 8;  // elements of half 0 (half 1 has DS % 8 fewer)
+        constexpr int P = (8 + NQ + 15) / 16;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (active) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(
+                v.rows + (size_t)id * v.row_stride + (size_t)h * v.half_bytes);
+            uint4 w[P];
+#pragma unroll
+            for (int p = 0; p < P; p++) w[p] = src[p];
+            const QLds q{yq + h * (v.half_bytes - 8)};
+            quant_half_sums<P, DS>(w, q, h, v.nch4, v.rem, acc);
+        }
+        const float b0 = pair_swap(acc[0]), b1 = pair_swap(acc[1]), b2 = pair_swap(acc[2]),
+                    b3 = pair_swap(acc[3]);
+        float s = 0.0f;
+        s += acc[0];
+        s += acc[1];
+        s += acc[2];
+        s += acc[3];
+        s += b0;
+        s += b1;
+        s += b2;
+        s += b3;
+        return __builtin_sqrtf(s);
+    } else if constexpr (DS > 0 && KIND == HNSW_VEC_F32) {
+        constexpr int P = (DS + 3) / 4;
+        float sm = 0.0f;
+        if (active) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(v.rows + (size_t)id * v.row_stride);
+            uint4 w[P];
+#pragma unroll
+            for (int p = 0; p < P; p++) w[p] = src[p];
+            sm = f32_row_sum<P, DS>(w, yq);
+        }
+        return __builtin_sqrtf(sm);
+    } else {
+        return dist_any_dim<KIND>(v, id, active, h, yq);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Per-wave search state and the pieces of search_layer
 // ---------------------------------------------------------------------------------------------
 template <int R>
@@ -1597,7 +1645,7 @@ hx_search2_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2
 // next layer's frontier.  The edges themselves are applied on the host with the
 // reference's make_connections / prune_connections / make_pruned_connections.
 // =============================================================================================
-template <int KIND>
+template <int KIND, int DS>
 __global__ void __launch_bounds__(64)
 hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1610,10 +1658,9 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
     const uint32_t vis_limit = hslots - (hslots >> 2);
     u64 *perm = reinterpret_cast<u64 *>(smem + 4ull * hslots);
     u64 *selk = perm + 64 * R;                                   // [64] selected keys
-    uint32_t *rejpos = reinterpret_cast<uint32_t *>(selk + 64);  // [512] rejected list positions
     const uint32_t yq_bytes =
         ((KIND == HNSW_VEC_QUANT8 ? 2u * (v.half_bytes - 8) * 4u : v.dim * 4u) + 15u) & ~15u;
-    float *yq = reinterpret_cast<float *>(rejpos + 512);
+    float *yq = reinterpret_cast<float *>(selk + 64);
     float *yqe = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(yq) + yq_bytes);
 
     constexpr int LPC = (KIND == HNSW_VEC_QUANT8) ? 2 : 1;
@@ -1643,7 +1690,7 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
     wl.last_key = KEY_INVALID;
 
     // one pass over up to CHUNK ids: optional visited filter, distance to the staged row, merge
-    auto process = [&](uint32_t id, bool valid, bool visit, uint32_t ef_l, u64 new_flag) {
+    auto process = [&](uint32_t id, bool valid, bool visit, uint32_t ef_l, u64 new_flag) __attribute__((always_inline)) {
         bool fresh = valid;
         if (visit) {
             bool f = false;
@@ -1652,7 +1699,7 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
             fresh = f;
         }
         if (__ballot(fresh && first) == 0) return;
-        const float dist = dist_any_dim<KIND>(v, id, fresh, h, yq);
+        const float dist = dist_build<KIND, DS>(v, id, fresh, h, yq);
         u64 key = KEY_INVALID;
         bool nan = false;
         if (fresh && first) {
@@ -1663,7 +1710,7 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
         wl.merge(key, ef_l, perm, lane, new_flag);
     };
     // expand every unexpanded entry of the list on `layer` (search_layer's loop, searcher.rs:35-95)
-    auto expand_all = [&](int layer, uint32_t ef_l, u64 new_flag) {
+    auto expand_all = [&](int layer, uint32_t ef_l, u64 new_flag) __attribute__((always_inline)) {
         const uint32_t S = layer == 0 ? v.S0 : v.S1;
         while (status == HNSW_OK) {
             const int cpos = wl.first_unexpanded(lane);
@@ -1706,7 +1753,7 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
         }
     };
     // start a layer: visited.clear(), candidates ∪= selected, visited ∪= ids(selected)
-    auto begin_layer = [&](uint32_t ef_l) {
+    auto begin_layer = [&](uint32_t ef_l) __attribute__((always_inline)) {
         for (uint32_t s = lane; s < (hslots >> 2); s += 64)
             reinterpret_cast<uint4 *>(htab)[s] =
                 make_uint4(HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT);
@@ -1741,53 +1788,83 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
         begin_layer(64u * R);
         expand_all(layer, 64u * R, KEY_EXPANDED);
         if (status != HNSW_OK) break;
+        // The reference pops the candidates in ascending order and accepts e iff (d(e,p), e) <
+        // (d(e,s), s) for every s selected so far (searcher.rs:128-139).  Equivalent, and parallel:
+        // whenever a candidate s is selected, every LATER candidate e with (d(s,e), s) < (d(e,p), e)
+        // is marked rejected (d is bit-symmetric); the next selection is the first unmarked one.
+        // Each round stages s once and evaluates up to 64 / LPC candidates per pass.
         const uint32_t n_c = wl.n_cur;
-        uint32_t ns = 0, nrej = 0;
-        for (uint32_t i = 0; i < n_c && ns < m; i++) {  // candidates.pop_first() in ascending order
-            u64 ek = 0;
+        uint32_t ns = 0;
+        uint32_t selbits = 0;  // bit r: the candidate at position 64 r + lane was selected
+#pragma unroll
+        for (int r = 0; r < R; r++) wl.L[r] &= KEY_MASK;  // the flag now means "rejected"
+        uint32_t cursor = 0;
+        while (ns < m && status == HNSW_OK) {
+            int pos = -1;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint32_t idx = 64u * r + lane;
+                const u64 mk = __ballot(idx >= cursor && idx < n_c && (wl.L[r] & KEY_EXPANDED) == 0);
+                if (pos < 0 && mk) pos = 64 * r + (__ffsll((long long)mk) - 1);
+            }
+            if (pos < 0) break;  // every candidate was popped
+            u64 sk_sel = 0;
 #pragma unroll
             for (int r = 0; r < R; r++)
-                if ((i >> 6) == (uint32_t)r) ek = readlane64(wl.L[r], i & 63) & KEY_MASK;
-            bool accept = true;
-            if (ns > 0) {
-                // nearest selected to e under Dist order: accept iff (d(e,p), e) < (d(e,s), s) for
-                // every selected s (searcher.rs:128-139) -- one ballot, no reduction
-                const uint32_t eid = (uint32_t)ek;
-                stage_row<KIND>(v, eid, yqe, lane);
-                bool worse = false;
-                for (uint32_t s0 = 0; s0 < ns; s0 += CHUNK) {
-                    const uint32_t j = s0 + cslot;
-                    const bool act = j < ns;
-                    const uint32_t sid = act ? (uint32_t)selk[j] : 0u;
-                    const float dist = dist_any_dim<KIND>(v, sid, act, h, yqe);
+                if ((pos >> 6) == r) {
+                    sk_sel = readlane64(wl.L[r], pos & 63);
+                    if (lane == (pos & 63)) selbits |= 1u << r;
+                }
+            if (lane == 0) selk[ns] = sk_sel;
+            ns++;
+            cursor = (uint32_t)pos + 1;
+            wave_fence();
+            if (ns >= m || cursor >= n_c) continue;  // nothing left to decide
+            const uint32_t sid = (uint32_t)sk_sel;
+            stage_row<KIND>(v, sid, yqe, lane);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint32_t idx = 64u * r + lane;
+                const bool open = idx >= cursor && idx < n_c && (wl.L[r] & KEY_EXPANDED) == 0;
+                if (__ballot(open) == 0) continue;
+                const uint32_t my_id = (uint32_t)wl.L[r], my_db = (uint32_t)(wl.L[r] >> 32);
+#pragma unroll
+                for (int half = 0; half < LPC; half++) {
+                    const int src = half * CHUNK + cslot;  // the lane that owns this pass's candidate
+                    const uint32_t cid = (uint32_t)__shfl((int)my_id, src);
+                    const uint32_t cdb = (uint32_t)__shfl((int)my_db, src);
+                    const bool act = __shfl(open ? 1 : 0, src) != 0;
+                    if (__ballot(act) == 0) continue;
+                    const float dist = dist_build<KIND, DS>(v, cid, act, h, yqe);
+                    bool rej = false;
                     if (act && first) {
                         if (dist != dist) status = HNSW_ERR_NAN_INPUT;
                         const u64 sk = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | sid;
-                        worse |= sk < ek;
+                        const u64 ck = ((u64)cdb << 32) | cid;
+                        rej = sk < ck;
                     }
+                    const u64 rm = __ballot(rej);  // bit LPC * cslot of the pass <-> owner lane src
+                    const int mine = lane - half * CHUNK;
+                    if (mine >= 0 && mine < CHUNK && ((rm >> (LPC * mine)) & 1)) wl.L[r] |= KEY_EXPANDED;
                 }
-                accept = __ballot(worse) == 0;
             }
-            if (accept) {
+            if (__ballot(status != HNSW_OK)) status = HNSW_ERR_NAN_INPUT;
+        }
+        // keep_pruned: fill up from the rejected candidates in ascending order (searcher.rs:141-146);
+        // only reached with ns < m when every candidate was popped
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t idx = 64u * r + lane;
+            u64 mk = __ballot(idx < n_c && (wl.L[r] & KEY_EXPANDED) != 0 && ((selbits >> r) & 1u) == 0);
+            while (mk && ns < m && status == HNSW_OK) {
+                const int j = __ffsll((long long)mk) - 1;
+                mk &= mk - 1;
+                const u64 ek = readlane64(wl.L[r], j) & KEY_MASK;
                 if (lane == 0) selk[ns] = ek;
                 ns++;
-            } else {
-                if (lane == 0) rejpos[nrej] = i;
-                nrej++;
             }
-            wave_fence();
         }
-        // keep_pruned: fill up from the rejected candidates in ascending order (searcher.rs:141-146)
-        for (uint32_t k = 0; k < nrej && ns < m; k++) {
-            const uint32_t i = rejpos[k];
-            u64 ek = 0;
-#pragma unroll
-            for (int r = 0; r < R; r++)
-                if ((i >> 6) == (uint32_t)r) ek = readlane64(wl.L[r], i & 63) & KEY_MASK;
-            if (lane == 0) selk[ns] = ek;
-            ns++;
-            wave_fence();
-        }
+        wave_fence();
         // save_layer_results + the selection seeds the next layer
         const u64 mine = (uint32_t)lane < ns ? selk[lane] : KEY_INVALID;
         if ((uint32_t)lane < ns) {
@@ -1858,14 +1935,18 @@ int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipSt
     const uint32_t slots_log2 = 12 + (a.ef_cons > 64 ? 1 : 0) + (a.ef_cons > 160 ? 1 : 0);
     const size_t yq_bytes =
         ((v.kind == HNSW_VEC_QUANT8 ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4) + 15) & ~15ull;
-    const size_t lds = (4ull << slots_log2) + 64ull * HX_MAX_R * 8 + 64 * 8 + 512 * 4 + 2 * yq_bytes;
+    const size_t lds = (4ull << slots_log2) + 64ull * HX_MAX_R * 8 + 64 * 8 + 2 * yq_bytes;
     if (lds > 160 * 1024) {
         set_error("insert kernel needs %zu bytes of LDS", lds);
         return HNSW_ERR_ARG;
     }
-    const void *kern = v.kind == HNSW_VEC_QUANT8
-                           ? reinterpret_cast<const void *>(hx_insert_kernel<HNSW_VEC_QUANT8>)
-                           : reinterpret_cast<const void *>(hx_insert_kernel<HNSW_VEC_F32>);
+    // the configs[1] dimension gets compile-time row loops
+    void (*kfn)(const DevView, const InsertArgs, const uint32_t);
+    if (v.kind == HNSW_VEC_QUANT8)
+        kfn = v.dim == 100 ? hx_insert_kernel<HNSW_VEC_QUANT8, 100> : hx_insert_kernel<HNSW_VEC_QUANT8, 0>;
+    else
+        kfn = v.dim == 100 ? hx_insert_kernel<HNSW_VEC_F32, 100> : hx_insert_kernel<HNSW_VEC_F32, 0>;
+    const void *kern = reinterpret_cast<const void *>(kfn);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
@@ -1873,12 +1954,7 @@ int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipSt
             return HNSW_ERR_HIP;
         }
     }
-    if (v.kind == HNSW_VEC_QUANT8)
-        hipLaunchKernelGGL(hx_insert_kernel<HNSW_VEC_QUANT8>, dim3(nblocks), dim3(64), lds, stream, v, a,
-                           slots_log2);
-    else
-        hipLaunchKernelGGL(hx_insert_kernel<HNSW_VEC_F32>, dim3(nblocks), dim3(64), lds, stream, v, a,
-                           slots_log2);
+    hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(64), lds, stream, v, a, slots_log2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("insert kernel launch: %s", hipGetErrorString(e));
@@ -1916,7 +1992,7 @@ __device__ __forceinline__ uint32_t edge_group_size(const uint64_t *keys, uint32
     }
 }
 
-template <int KIND>
+template <int KIND, int DS>
 __global__ void __launch_bounds__(64)
 hx_connect_kernel(const DevView v, const ConnectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1969,7 +2045,7 @@ hx_connect_kernel(const DevView v, const ConnectArgs a) {
         const uint32_t id = (uint32_t)__shfl((int)cur, (int)(slot & 63));
         const bool act = slot < S && id < v.n_points;
         if (slot < S && id != HX_EMPTY_SLOT && id >= v.n_points) *a.status = HNSW_ERR_NODE_NOT_IN_GRAPH;
-        const float dist = dist_any_dim<KIND>(v, id, act, h, yq);
+        const float dist = dist_build<KIND, DS>(v, id, act, h, yq);
         u64 key = KEY_INVALID;
         if (act && first) {
             key = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | id;
@@ -2058,10 +2134,12 @@ int launch_connect(const DevView &v, const ConnectArgs &a, hipStream_t stream) {
     const size_t yq_bytes =
         ((v.kind == HNSW_VEC_QUANT8 ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4) + 15) & ~15ull;
     const size_t lds = 2 * 64 * 8 + yq_bytes;
+    void (*kfn)(const DevView, const ConnectArgs);
     if (v.kind == HNSW_VEC_QUANT8)
-        hipLaunchKernelGGL(hx_connect_kernel<HNSW_VEC_QUANT8>, dim3(a.count), dim3(64), lds, stream, v, a);
+        kfn = v.dim == 100 ? hx_connect_kernel<HNSW_VEC_QUANT8, 100> : hx_connect_kernel<HNSW_VEC_QUANT8, 0>;
     else
-        hipLaunchKernelGGL(hx_connect_kernel<HNSW_VEC_F32>, dim3(a.count), dim3(64), lds, stream, v, a);
+        kfn = v.dim == 100 ? hx_connect_kernel<HNSW_VEC_F32, 100> : hx_connect_kernel<HNSW_VEC_F32, 0>;
+    hipLaunchKernelGGL(kfn, dim3(a.count), dim3(64), lds, stream, v, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("connect kernel launch: %s", hipGetErrorString(e));
