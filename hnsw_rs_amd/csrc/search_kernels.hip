@@ -43,6 +43,7 @@ namespace hx {
 typedef unsigned long long u64;
 
 static constexpr u64 KEY_INVALID = ~0ull;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 static constexpr u64 KEY_MASK = 0x7FFFFFFFFFFFFFFFull;  // drops the expanded flag
 static constexpr u64 KEY_EXPANDED = 1ull << 63;
 
@@ -116,10 +117,31 @@ __device__ __forceinline__ void quant_half_sums(const uint4 (&w)[P], const QSrc 
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (p == 0 && j < 2) continue;  // header
+            if (DS > 0) {
+                // compile-time dimension: dead elements vanish; the four bytes of a chunk dword feed
+                // running sums 0..3 as two packed pairs (v_pk_mul_f32 / v_pk_add_f32: per element the
+                // same correctly rounded operations as the scalar form)
+                constexpr int N4 = 4 * (DS / 8);
+                const int e0 = 16 * p + 4 * j - 8;
+                if (e0 + 3 < N4) {
+#pragma unroll
+                    for (int k = 0; k < 4; k += 2) {
+                        const f32x2 c = {(float)((dw[j] >> (8 * k)) & 0xFFu),
+                                         (float)((dw[j] >> (8 * (k + 1))) & 0xFFu)};
+                        const f32x2 x = c * delta + mn;
+                        const f32x2 y = {yq[e0 + k], yq[e0 + k + 1]};
+                        const f32x2 t = x - y;
+                        const f32x2 t2 = t * t;
+                        acc[k] += t2.x;
+                        acc[k + 1] += t2.y;
+                    }
+                    continue;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int e = 16 * p + 4 * j + k - 8;
-                if (DS > 0) {  // compile-time dimension: dead elements vanish
+                if (DS > 0) {  // the tail of a compile-time dimension
                     constexpr int N4 = 4 * (DS / 8), RM = DS % 8;
                     if (e >= N4 + RM) continue;
                     const float x = ((float)((dw[j] >> (8 * k)) & 0xFFu) * delta) + mn;
@@ -424,16 +446,27 @@ __device__ __forceinline__ uint4 asm_ld128(const void *p) {
 // reference's single left-to-right chain (full.rs:24-28).
 template <int P, int DS>
 __device__ __forceinline__ float f32_row_sum(const uint4 (&w)[P], const float *yq) {
+    // x - y and the square run two elements per instruction (v_pk_add_f32 / v_pk_mul_f32: each
+    // element is the same correctly rounded IEEE operation); the sum stays the one serial chain
     float s = 0.0f;
 #pragma unroll
     for (int p = 0; p < P; p++) {
         const uint32_t dw[4] = {w[p].x, w[p].y, w[p].z, w[p].w};
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < 4; j += 2) {
             const int e = 4 * p + j;
             if (e >= DS) continue;
-            const float t = __builtin_bit_cast(float, dw[j]) - yq[e];
-            s += t * t;
+            if (e + 1 < DS) {
+                const f32x2 x = {__builtin_bit_cast(float, dw[j]), __builtin_bit_cast(float, dw[j + 1])};
+                const f32x2 y = {yq[e], yq[e + 1]};
+                const f32x2 t = x - y;
+                const f32x2 t2 = t * t;
+                s += t2.x;
+                s += t2.y;
+            } else {
+                const float t = __builtin_bit_cast(float, dw[j]) - yq[e];
+                s += t * t;
+            }
         }
     }
     return s;
