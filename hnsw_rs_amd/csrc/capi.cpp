@@ -132,7 +132,7 @@ int search_host(hnsw_index *h, hx::SearchArgs a_host, const float *Q, uint64_t n
     }
     std::vector<hnsw_query_stats> st(nq);
     uint32_t ef_max = std::max(a.ef_bottom, a.ef_upper);
-    uint32_t slots = hx::default_slots_log2(ef_max);
+    uint32_t slots = hx::default_slots_log2(ef_max, v.S0);
     uint64_t nrun = nq;
     std::vector<uint32_t> sel;
     while (true) {

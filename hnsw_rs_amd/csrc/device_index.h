@@ -156,6 +156,7 @@ uint32_t adj_stride(uint64_t cap, uint32_t min_slots);
 int launch_search(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint32_t slots_log2,
                   hipStream_t stream);
 uint32_t default_slots_log2(uint32_t ef);
+uint32_t default_slots_log2(uint32_t ef, uint32_t s0);
 uint32_t max_slots_log2(uint32_t ef);
 
 int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipStream_t stream);

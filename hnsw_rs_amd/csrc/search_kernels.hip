@@ -2208,12 +2208,20 @@ int launch_scatter_rows(uint32_t *dst, uint32_t S, const uint32_t *d_row_index, 
 // launchers
 // ---------------------------------------------------------------------------------------------
 
-uint32_t default_slots_log2(uint32_t ef) {
-    if (ef <= 96) return 12;   // 4096 slots, 16 KiB
-    if (ef <= 224) return 13;
-    if (ef <= 448) return 14;
-    return 15;                 // 128 KiB
+// Visited-table size for a search with list size ef on rows of up to s0 neighbours.  The table must
+// hold every id whose distance is computed in one layer: measured means are 18.5 ef at ef <= 128
+// falling to 13 ef at ef = 256 for 32-slot rows (1M..10M points); the limit (75 % of the slots) is
+// kept >= 1.5 x that.  Too small is safe (status OVERFLOW; the host-pointer API retries with the
+// next size), too large costs occupancy: 64 KiB tables leave 2 waves per CU, i.e. a 1024-query
+// launch no longer fits the chip in one round.
+uint32_t default_slots_log2(uint32_t ef, uint32_t s0) {
+    const uint64_t e = (uint64_t)ef * std::max(s0, 8u) / 32u;  // ef in units of 32-slot rows
+    if (e <= 96) return 12;   // 4096 slots, 16 KiB: limit 3072
+    if (e <= 288) return 13;  // 8192 slots, 32 KiB: limit 6144
+    if (e <= 640) return 14;  // 64 KiB
+    return 15;                // 128 KiB
 }
+uint32_t default_slots_log2(uint32_t ef) { return default_slots_log2(ef, 32); }
 uint32_t max_slots_log2(uint32_t) { return 15; }
 
 template <int KIND, int P, int DS, int R, bool FAT>
@@ -2300,7 +2308,11 @@ static int launch_r(const DevView &v, const SearchArgs &a, uint32_t nblocks, uin
             if (ef_max <= 512) return launch_two<P, DS, 8>(v, a, nblocks, slots_log2, stream);
         }
     }
-    if (CAN_FAT && v.fat != nullptr && v.S0 == 32 && a.layer_lo == 0) {
+    // the inline-rows loop stages two block images in LDS; it is used while a wave still needs no more
+    // than a quarter of the CU's LDS, so that 1024 waves fit the chip in one round
+    const uint32_t r_list = ef_max <= 64 ? 1 : ef_max <= 128 ? 2 : ef_max <= 256 ? 4 : 8;
+    const size_t fat_lds = (4ull << slots_log2) + 64ull * r_list * 8 + 2ull * 1024 * (P > 0 ? P : 1) + 1024;
+    if (CAN_FAT && v.fat != nullptr && v.S0 == 32 && a.layer_lo == 0 && fat_lds <= 40 * 1024) {
         if (ef_max <= 64) return launch_one<KIND, P, DS, 1, CAN_FAT>(v, a, nblocks, slots_log2, stream);
         if (ef_max <= 128) return launch_one<KIND, P, DS, 2, CAN_FAT>(v, a, nblocks, slots_log2, stream);
         if (ef_max <= 256) return launch_one<KIND, P, DS, 4, CAN_FAT>(v, a, nblocks, slots_log2, stream);
@@ -2320,7 +2332,7 @@ int launch_search(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint3
     uint32_t ef_max = std::max(1u, a.ef_bottom);
     if (a.layer_hi > a.layer_lo) ef_max = std::max(ef_max, a.ef_upper);
     if (a.entries) ef_max = std::max(ef_max, a.n_entry);
-    if (slots_log2 == 0) slots_log2 = default_slots_log2(ef_max);
+    if (slots_log2 == 0) slots_log2 = default_slots_log2(ef_max, v.S0);
     if (v.kind == HNSW_VEC_QUANT8) {
         const uint32_t P = v.half_bytes / 16;
         if (v.dim == 100) return launch_r<HNSW_VEC_QUANT8, 4, 100>(v, a, nblocks, slots_log2, stream, ef_max);

@@ -6,18 +6,19 @@ import hnsw_rs_amd as H
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 kind = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 d, m = 100, 16
+recipe = int(os.environ.get('RECIPE', '0'))
 thr = min(32, os.cpu_count())
-vs = H.synth_rows(0, 0x5EED0001, 0, N, d, thr); qs = H.synth_rows(0, 0x5EED0002, 0, 1024, d, 8)
+vs = H.synth_rows(recipe, 0x5EED0001, 0, N, d, thr); qs = H.synth_rows(recipe, 0x5EED0002, 0, 1024, d, 8)
 mode = int(os.environ.get('MODE', '2'))
 dev = H.HNSW.new(m, 32, d, kind); dev.set_option('gpu_build', mode)
 t = time.time(); dev.insert_bulk_device(vs, thr, True); t_dev = time.time() - t
 print('device build %.1fs layers=%d compliant=%s' % (t_dev, dev.nb_layers(), dev.assert_param_compliance()), flush=True)
 truth, _ = dev.brute_force(qs, 10)
-for ef in (64, 96):
+for ef in (64, 96, 256):
     ids, _, _, st = dev.search_batch(qs, 10, ef)
     print('device-built ef=%d recall %.4f n_dist %.0f' % (ef, sum(len(set(a) & set(b)) for a, b in zip(ids.tolist(), truth.tolist())) / 10240, st[:, 0].mean()), flush=True)
 if len(sys.argv) > 3:
     t = time.time(); cpu = H.HNSW.new(m, 32, d, kind).insert_bulk(vs, thr, False); print('cpu build %.1fs' % (time.time() - t), flush=True)
-    for ef in (64, 96):
+    for ef in (64, 96, 256):
         ids, _, _, st = cpu.search_batch(qs, 10, ef)
         print('cpu-built ef=%d recall %.4f n_dist %.0f' % (ef, sum(len(set(a) & set(b)) for a, b in zip(ids.tolist(), truth.tolist())) / 10240, st[:, 0].mean()), flush=True)
