@@ -657,6 +657,20 @@ struct WaveList {
 // long as its unluckiest lane (4-5 rounds at 30 % load).  Slots fill left to right and never empty,
 // ids within one adjacency row are distinct, so "absent from the bucket, first empty slot claimed"
 // is an exact insert.  Returns true when id was not present.
+// read-only membership test of the same table (speculative evaluation: nothing may be inserted yet)
+__device__ __forceinline__ bool visited_contains(const uint32_t *tab, uint32_t hmask, uint32_t slots_log2,
+                                                 uint32_t id) {
+    const uint32_t bmask = hmask >> 2;
+    uint32_t b = (id * 0x9E3779B1u) >> (32 - (slots_log2 - 2));
+    while (true) {
+        const uint4 bk = *reinterpret_cast<const uint4 *>(tab + 4 * b);
+        if (bk.x == id || bk.y == id || bk.z == id || bk.w == id) return true;
+        if (bk.x == HX_EMPTY_SLOT || bk.y == HX_EMPTY_SLOT || bk.z == HX_EMPTY_SLOT || bk.w == HX_EMPTY_SLOT)
+            return false;
+        b = (b + 1) & bmask;
+    }
+}
+
 __device__ __forceinline__ bool visited_insert(uint32_t *tab, uint32_t hmask, uint32_t slots_log2,
                                                uint32_t id) {
     const uint32_t bmask = hmask >> 2;
@@ -734,7 +748,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
     wl.last_key = KEY_INVALID;
 
     // ---- distance of one candidate per lane group; returns the key on the group's first lane
-    auto eval_key = [&](uint32_t id, bool active, bool hidden_loads) -> u64 {
+    auto eval_dist = [&](uint32_t id, bool active, bool hidden_loads) __attribute__((always_inline)) -> float {
         float dist = 0.0f;
         if (KIND == HNSW_VEC_QUANT8 && P > 0) {
             float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -780,6 +794,10 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
         } else {
             dist = dist_any_dim<KIND>(v, id, active, h, yq);
         }
+        return dist;
+    };
+    auto eval_key = [&](uint32_t id, bool active, bool hidden_loads) -> u64 {
+        const float dist = eval_dist(id, active, hidden_loads);
         const bool first = (LPC == 1) || (h == 0);
         if (!(active && first)) return KEY_INVALID;
         if (dist != dist) {
@@ -1025,6 +1043,127 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                     }
                 }
             }
+            }
+            continue;
+        }
+
+        if (KIND == HNSW_VEC_F32 && !FAT && layer == 0 && S <= 32) {
+            // ---- layer 0, one lane per neighbour, rows of at most 32 slots: TWO rows per pass.
+            // Lanes 0..31 take the row of the candidate c being expanded, lanes 32..63 the row of the
+            // runner-up p (the smallest unexpanded entry once c is marked).  Both adjacency rows and
+            // both sets of vector rows are fetched together, one pass evaluates all of them.  c is
+            // committed (visited insert, merge); if p is then still the smallest unexpanded entry --
+            // measured: 2 times out of 3 -- it is committed from the distances already in registers,
+            // i.e. that expansion costs no memory round trip and no distance pass.  Otherwise p's
+            // results are dropped.  Nothing of p touches the visited set or the list before its
+            // commit, and the commit filters against everything c inserted, so the expanded nodes,
+            // the fresh sets, the counters and the result are those of the one-at-a-time loop.
+            int cpos = wl.first_unexpanded(lane);  // carried: the pick after a merge is the next c
+            while (status == HNSW_OK) {
+                if (cpos < 0) break;
+                uint32_t cid = 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if ((cpos >> 6) == r) {
+                        cid = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wl.L[r], cpos & 63);
+                        if (lane == (cpos & 63)) wl.L[r] |= KEY_EXPANDED;
+                    }
+                }
+                n_exp++;
+                const int ppos = wl.first_unexpanded(lane);
+                uint32_t pid = cid;
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    if (ppos >= 0 && (ppos >> 6) == r)
+                        pid = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wl.L[r], ppos & 63);
+                const bool upper = lane >= 32;
+                const uint32_t slot = (uint32_t)lane & 31u;
+                uint32_t nb = HX_EMPTY_SLOT;
+                if (slot < S && (!upper || ppos >= 0)) nb = v.adj0[(size_t)(upper ? pid : cid) * S + slot];
+                const bool is_ptr = nb != HX_EMPTY_SLOT && (nb & HX_OVF_FLAG);
+                const bool valid = nb != HX_EMPTY_SLOT && !is_ptr;
+                const u64 pm = __ballot(is_ptr);
+                // a runner-up row with an overflow pointer is not speculated on
+                const bool spec_ok = ppos >= 0 && (pm >> 32) == 0;
+                uint32_t ovf = HX_EMPTY_SLOT;
+                if (pm & 0xFFFFFFFFull)
+                    ovf = (uint32_t)__builtin_amdgcn_readlane((int)nb, __ffsll((long long)(pm & 0xFFFFFFFFull)) - 1) &
+                          ~HX_OVF_FLAG;
+                // ---- c: filter now; p: read-only look-up (its insert happens at its commit)
+                const u64 vmask = __ballot(valid);
+                const uint32_t cnt_c = (uint32_t)__popcll(vmask & 0xFFFFFFFFull);
+                const uint32_t cnt_p = (uint32_t)__popcll(vmask >> 32);
+                sum_deg += cnt_c;
+                if (n_vis + cnt_c > vis_limit) {
+                    status = HNSW_ERR_OVERFLOW;
+                    break;
+                }
+                n_vis += cnt_c;
+                bool want = false;
+                if (valid && !upper) want = visited_insert(htab, hmask, slots_log2, nb);
+                // (the look-up runs after the inserts of this pass: what c just claimed is skipped)
+                wave_fence();
+                if (valid && upper && spec_ok) want = !visited_contains(htab, hmask, slots_log2, nb);
+                n_dist += (uint32_t)__popcll(__ballot(want && !upper));
+                float dist = 0.0f;
+                if (__ballot(want)) dist = eval_dist(nb, want, false);
+                const bool nan = want && dist != dist;
+                if (__ballot(nan && !upper)) {
+                    status = HNSW_ERR_NAN_INPUT;
+                    break;
+                }
+                const u64 key = (want && !nan) ? (((u64)__builtin_bit_cast(uint32_t, dist) << 32) | nb) : KEY_INVALID;
+                wl.merge(upper ? KEY_INVALID : key, ef_l, perm, lane);
+                if (ovf != HX_EMPTY_SLOT) {  // degree > S: the rest of c's row
+                    const uint32_t lo = v.ovf_off[ovf], hi = v.ovf_off[ovf + 1];
+                    for (uint32_t base = lo; base < hi; base += CHUNK) {
+                        const uint32_t i = base + cslot;
+                        const bool ov = i < hi;
+                        const uint32_t onb = ov ? v.ovf_nbrs[i] : HX_EMPTY_SLOT;
+                        const uint32_t ocnt = (uint32_t)__popcll(__ballot(ov && h == 0));
+                        sum_deg += ocnt;
+                        if (n_vis + ocnt > vis_limit) {
+                            status = HNSW_ERR_OVERFLOW;
+                            break;
+                        }
+                        n_vis += ocnt;
+                        process(onb, ov, true, ef_l);
+                        if (status != HNSW_OK) break;
+                    }
+                    if (status != HNSW_OK) break;
+                }
+                // ---- is p the next candidate?  then commit it from the registers
+                const int npos = wl.first_unexpanded(lane);
+                cpos = npos;
+                if (npos < 0) break;
+                if (!spec_ok) continue;
+                uint32_t nid = 0;
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    if ((npos >> 6) == r)
+                        nid = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wl.L[r], npos & 63);
+                if (nid != pid) continue;
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    if ((npos >> 6) == r && lane == (npos & 63)) wl.L[r] |= KEY_EXPANDED;
+                n_exp++;
+                sum_deg += cnt_p;
+                if (n_vis + cnt_p > vis_limit) {
+                    status = HNSW_ERR_OVERFLOW;
+                    break;
+                }
+                n_vis += cnt_p;
+                // every valid neighbour of p goes through the filter now: one that c's commit inserted
+                // meanwhile is dropped, one that was skipped above was in the set already
+                bool fresh = false;
+                if (valid && upper) fresh = visited_insert(htab, hmask, slots_log2, nb);
+                n_dist += (uint32_t)__popcll(__ballot(fresh));
+                if (__ballot(fresh && nan)) {
+                    status = HNSW_ERR_NAN_INPUT;
+                    break;
+                }
+                wl.merge((fresh && upper) ? key : KEY_INVALID, ef_l, perm, lane);
+                cpos = wl.first_unexpanded(lane);
             }
             continue;
         }
