@@ -42,6 +42,10 @@ extern "C" {
     pub fn hnsw_get_params(h: *const HnswIndex, out: *mut HnswParams) -> c_int;
     pub fn hnsw_set_ep(h: *mut HnswIndex, ep: u32) -> c_int;
     pub fn hnsw_insert_bulk(h: *mut HnswIndex, rows: *const f32, n: u64, nb_threads: u32, verbose: c_int) -> c_int;
+    pub fn hnsw_insert_bulk_device(
+        h: *mut HnswIndex, rows: *const f32, n: u64, nb_threads: u32, verbose: c_int, levels: *const u8,
+    ) -> c_int;
+    pub fn hnsw_set_option(h: *mut HnswIndex, key: *const c_char, value: i64) -> c_int;
     pub fn hnsw_insert_vec(h: *mut HnswIndex, v: *const f32, out_id: *mut u32) -> c_int;
     pub fn hnsw_search(h: *mut HnswIndex, q: *const f32, n: u32, ef: u32, ids: *mut u32, count: *mut u32) -> c_int;
     pub fn hnsw_search_batch(

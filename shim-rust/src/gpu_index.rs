@@ -105,6 +105,16 @@ impl HNSW {
         Self::from_handle(h)
     }
 
+    /// Not in the reference: route later `insert_bulk` calls to the on-device build (searches,
+    /// heuristic, connect and prune on the GPU).  The graph is a valid HNSW graph
+    /// of the same recall, not the identical one the CPU algorithm would produce.
+    pub fn gpu_build(self, on: bool) -> Self {
+        let key = std::ffi::CString::new("gpu_build").unwrap();
+        let rc = unsafe { hnsw_set_option(self.handle, key.as_ptr(), if on { 2 } else { 0 }) };
+        assert_eq!(rc, HNSW_OK, "{}", last_error());
+        self
+    }
+
     /// template.rs:388-444 (consumes and returns the index)
     pub fn insert_bulk(mut self, vectors: Vec<Vec<f32>>, nb_threads: usize, verbose: bool) -> Result<HNSW, String> {
         let dim = self.params.dim;
