@@ -95,22 +95,25 @@ def test_dimensions_and_vector_kinds(kind, d):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
 @pytest.mark.parametrize("ef", [65, 128, 200, 300, 512])
-def test_large_ef_uses_wider_lists(ef):
+def test_large_ef_uses_wider_lists(ef, kind):
     n, d, m = 3000, 24, 16
     vs, qs = rand_vectors(n, d, 1), rand_vectors(32, d, 2)
-    index, orc = both(vs, O.draw_levels(n, m, 9), m, threads=4)
+    index, orc = both(vs, O.draw_levels(n, m, 9), m, kind=kind, threads=4)
     assert_search_equal(index.search_batch(qs, 100, ef), orc.search_batch(qs, 100, ef), "ef=%d" % ef)
     with pytest.raises(H.HnswError):
         index.search_batch(qs, 10, 513)
 
 
-def test_rows_longer_than_the_adjacency_stride():
-    """degree > stride happens; such rows spill into the overflow CSR"""
+@pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
+def test_rows_longer_than_the_adjacency_stride(kind):
+    """degree > stride happens; such rows spill into the overflow CSR -- also when the row
+    belongs to the runner-up that the f32 loop evaluates speculatively"""
     n, d, m = 400, 12, 4  # layer-0 cap 8, stride 32
     vs, qs = rand_vectors(n, d, 3), rand_vectors(50, d, 4)
     lv = O.draw_levels(n, m, 3)
-    orc = O.OracleHNSW(m, None, d).insert_bulk(vs, lv)
+    orc = O.OracleHNSW(m, None, d, kind).insert_bulk(vs, lv)
     # graft 70 extra symmetric edges onto node 5 and 40 onto node 9 of layer 0
     ids, offs, nbrs = orc.layer_csr(0)
     adj = {int(i): set(int(x) for x in nbrs[int(offs[k]):int(offs[k + 1])]) for k, i in enumerate(ids)}
@@ -121,7 +124,7 @@ def test_rows_longer_than_the_adjacency_stride():
     rows = [sorted(adj[int(i)]) for i in ids]
     offs2 = np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64)
     nbrs2 = np.concatenate([np.array(r, dtype=np.uint32) for r in rows])
-    orc2 = O.OracleHNSW(m, None, d)
+    orc2 = O.OracleHNSW(m, None, d, kind)
     orc2.import_points(vs, lv)
     orc2.import_layer(0, ids, offs2, nbrs2)
     for l in range(1, orc.nb_layers):
@@ -136,13 +139,14 @@ def test_rows_longer_than_the_adjacency_stride():
                                 "overflow ef=%d inline=%d" % (ef, inline_rows))
 
 
-def test_duplicate_and_constant_vectors():
+@pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
+def test_duplicate_and_constant_vectors(kind):
     """ties are broken by id (dist.rs:30-38); constant vectors quantise through a NaN (Q2)"""
     d = 20
     base = rand_vectors(50, d, 8)
     vs = np.concatenate([base, base, np.full((10, d), 0.25, np.float32), base[:20]])
     lv = O.draw_levels(len(vs), 6, 4)
-    index, orc = both(vs, lv, 6)
+    index, orc = both(vs, lv, 6, kind=kind)
     qs = np.concatenate([base[:20], np.full((2, d), 0.25, np.float32), rand_vectors(10, d, 9)])
     for ef in (1, 8, 40):
         assert_search_equal(index.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef), "ties ef=%d" % ef)
@@ -157,11 +161,12 @@ def test_nan_query_is_an_error_not_a_result(glove):
     assert e.value.code == _lib.ERR_NAN_INPUT
 
 
-def test_tiny_indexes():
+@pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
+def test_tiny_indexes(kind):
     for n in (1, 2, 3, 40):
         vs = rand_vectors(n, 9, n)
         lv = O.draw_levels(n, 4, n)
-        index, orc = both(vs, lv, 4)
+        index, orc = both(vs, lv, 4, kind=kind)
         qs = rand_vectors(5, 9, 77)
         assert_search_equal(index.search_batch(qs, 10, 16), orc.search_batch(qs, 10, 16), "n=%d" % n)
     with pytest.raises(H.HnswError):
