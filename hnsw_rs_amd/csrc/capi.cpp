@@ -21,12 +21,29 @@
 
 using hx::set_error;
 
+// Per-call scratch of the host-pointer search entry points: one device arena, one pinned host arena
+// and a stream, kept in a pool on the handle so that a call costs no allocation, one H2D and one D2H
+// copy.  Concurrent callers each take their own scratch (hnsw_search* stays re-entrant).
+struct SearchScratch {
+    void *dev = nullptr, *pin = nullptr;
+    size_t dev_cap = 0, pin_cap = 0;
+    hipStream_t stream = nullptr;
+    int device = -1;
+    ~SearchScratch() {
+        if (dev) (void)hipFree(dev);
+        if (pin) (void)hipHostFree(pin);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
 struct hnsw_index {
     std::unique_ptr<hx::HostIndex> host;
     hx::DeviceIndex dev;
     int device = -1;
     int gpu_build = 0;  // option "gpu_build": insert_bulk runs the on-device build (1 host connect, 2 device connect)
     std::mutex mu;
+    std::mutex pool_mu;
+    std::vector<std::unique_ptr<SearchScratch>> pool;
 };
 
 namespace {
@@ -105,6 +122,50 @@ hx::SearchArgs ann_args(const hx::DevView &v, const float *dQ, uint32_t n, uint3
     return a;
 }
 
+struct ScratchLease {  // takes a scratch from the handle's pool, gives it back at scope exit
+    hnsw_index *h;
+    std::unique_ptr<SearchScratch> s;
+    explicit ScratchLease(hnsw_index *hh) : h(hh) {
+        std::lock_guard<std::mutex> g(h->pool_mu);
+        if (!h->pool.empty()) {
+            s = std::move(h->pool.back());
+            h->pool.pop_back();
+        }
+    }
+    ~ScratchLease() {
+        if (!s) return;
+        std::lock_guard<std::mutex> g(h->pool_mu);
+        if (h->pool.size() < 16) h->pool.push_back(std::move(s));
+    }
+    int prepare(int device, size_t dev_bytes, size_t pin_bytes) {
+        if (s && s->device != device) s.reset();
+        if (!s) {
+            s.reset(new SearchScratch());
+            s->device = device;
+            HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        }
+        if (s->dev_cap < dev_bytes) {
+            if (s->dev) (void)hipFree(s->dev);
+            s->dev = nullptr;
+            s->dev_cap = 0;
+            const size_t cap = dev_bytes + dev_bytes / 4 + 4096;
+            HIP_TRY(hipMalloc(&s->dev, cap));
+            s->dev_cap = cap;
+        }
+        if (s->pin_cap < pin_bytes) {
+            if (s->pin) (void)hipHostFree(s->pin);
+            s->pin = nullptr;
+            s->pin_cap = 0;
+            const size_t cap = pin_bytes + pin_bytes / 4 + 4096;
+            HIP_TRY(hipHostMalloc(&s->pin, cap, hipHostMallocDefault));
+            s->pin_cap = cap;
+        }
+        return HNSW_OK;
+    }
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 // host-pointer search with the overflow retry: queries whose visited table filled up are run
 // again with a table twice the size
 int search_host(hnsw_index *h, hx::SearchArgs a_host, const float *Q, uint64_t nq, uint32_t *ids,
@@ -113,46 +174,51 @@ int search_host(hnsw_index *h, hx::SearchArgs a_host, const float *Q, uint64_t n
     if (rc != HNSW_OK) return rc;
     const hx::DevView &v = h->dev.view;
     const uint32_t n = a_host.n, d = v.dim;
-    DevBuf dQ, dIds, dDists, dCounts, dStats, dSel, dEnt;
-    if ((rc = dQ.alloc(nq * d * 4)) || (rc = dIds.alloc(nq * n * 4)) ||
-        (rc = dDists.alloc(nq * n * 4)) || (rc = dCounts.alloc(nq * 4)) ||
-        (rc = dStats.alloc(nq * sizeof(hnsw_query_stats))) || (rc = dSel.alloc(nq * 4)))
-        return rc;
-    HIP_TRY(hipMemcpy(dQ.p, Q, nq * d * 4, hipMemcpyHostToDevice));
+    // device arena: [queries | selection | entries | ids | dists | counts | stats]; the last four are
+    // one contiguous block that comes back in a single copy
+    const size_t o_q = 0, o_sel = o_q + align256(nq * d * 4), o_ent = o_sel + align256(nq * 4),
+                 o_out = o_ent + align256((size_t)(entries ? a_host.n_entry : 0) * 4);
+    const size_t r_ids = 0, r_dists = r_ids + align256(nq * n * 4), r_counts = r_dists + align256(nq * n * 4),
+                 r_stats = r_counts + align256(nq * 4), out_bytes = r_stats + align256(nq * sizeof(hnsw_query_stats));
+    ScratchLease lease(h);
+    if ((rc = lease.prepare(h->dev.device, o_out + out_bytes, out_bytes))) return rc;
+    SearchScratch &s = *lease.s;
+    unsigned char *dv = static_cast<unsigned char *>(s.dev), *hv = static_cast<unsigned char *>(s.pin);
+    HIP_TRY(hipMemcpyAsync(dv + o_q, Q, nq * d * 4, hipMemcpyHostToDevice, s.stream));
     hx::SearchArgs a = a_host;
-    a.Q = dQ.as<float>();
-    a.out_ids = dIds.as<uint32_t>();
-    a.out_dists = dDists.as<float>();
-    a.out_counts = dCounts.as<uint32_t>();
-    a.out_stats = dStats.as<hnsw_query_stats>();
+    a.Q = reinterpret_cast<const float *>(dv + o_q);
+    a.out_ids = reinterpret_cast<uint32_t *>(dv + o_out + r_ids);
+    a.out_dists = reinterpret_cast<float *>(dv + o_out + r_dists);
+    a.out_counts = reinterpret_cast<uint32_t *>(dv + o_out + r_counts);
+    a.out_stats = reinterpret_cast<hnsw_query_stats *>(dv + o_out + r_stats);
     if (entries) {
-        if ((rc = dEnt.alloc((size_t)a.n_entry * 4))) return rc;
-        HIP_TRY(hipMemcpy(dEnt.p, entries, (size_t)a.n_entry * 4, hipMemcpyHostToDevice));
-        a.entries = dEnt.as<uint32_t>();
+        HIP_TRY(hipMemcpyAsync(dv + o_ent, entries, (size_t)a.n_entry * 4, hipMemcpyHostToDevice, s.stream));
+        a.entries = reinterpret_cast<const uint32_t *>(dv + o_ent);
     }
-    std::vector<hnsw_query_stats> st(nq);
+    const hnsw_query_stats *st = reinterpret_cast<const hnsw_query_stats *>(hv + r_stats);
     uint32_t ef_max = std::max(a.ef_bottom, a.ef_upper);
     uint32_t slots = hx::default_slots_log2(ef_max, v.S0);
     uint64_t nrun = nq;
     std::vector<uint32_t> sel;
     while (true) {
-        rc = hx::launch_search(v, a, (uint32_t)nrun, slots, nullptr);
+        rc = hx::launch_search(v, a, (uint32_t)nrun, slots, s.stream);
         if (rc != HNSW_OK) return rc;
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(st.data(), dStats.p, nq * sizeof(hnsw_query_stats), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(hv, dv + o_out, out_bytes, hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(hipStreamSynchronize(s.stream));
         sel.clear();
         for (uint64_t i = 0; i < nq; i++)
             if (st[i].status == HNSW_ERR_OVERFLOW) sel.push_back((uint32_t)i);
         if (sel.empty() || slots >= hx::max_slots_log2(ef_max)) break;
         slots++;
-        HIP_TRY(hipMemcpy(dSel.p, sel.data(), sel.size() * 4, hipMemcpyHostToDevice));
-        a.qsel = dSel.as<uint32_t>();
+        HIP_TRY(hipMemcpyAsync(dv + o_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, s.stream));
+        HIP_TRY(hipStreamSynchronize(s.stream));  // `sel` is reused by the next round
+        a.qsel = reinterpret_cast<const uint32_t *>(dv + o_sel);
         nrun = sel.size();
     }
-    HIP_TRY(hipMemcpy(ids, dIds.p, nq * n * 4, hipMemcpyDeviceToHost));
-    if (dists) HIP_TRY(hipMemcpy(dists, dDists.p, nq * n * 4, hipMemcpyDeviceToHost));
-    if (counts) HIP_TRY(hipMemcpy(counts, dCounts.p, nq * 4, hipMemcpyDeviceToHost));
-    if (stats) memcpy(stats, st.data(), nq * sizeof(hnsw_query_stats));
+    memcpy(ids, hv + r_ids, nq * n * 4);
+    if (dists) memcpy(dists, hv + r_dists, nq * n * 4);
+    if (counts) memcpy(counts, hv + r_counts, nq * 4);
+    if (stats) memcpy(stats, st, nq * sizeof(hnsw_query_stats));
     for (uint64_t i = 0; i < nq; i++) {
         if (st[i].status != HNSW_OK) {
             switch (st[i].status) {

@@ -310,6 +310,29 @@ def test_bert_sized_vectors(kind):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+def test_host_pointer_search_is_reentrant(glove):
+    """ann_by_vector takes &self in the reference (template.rs:306): concurrent callers on one handle;
+    every call leases its own scratch and stream"""
+    import threading
+    index, orc, queries = glove
+    want = orc.search_batch(queries, 10, 48)
+    got, errs = [None] * 6, []
+
+    def work(t):
+        try:
+            for _ in range(5):
+                got[t] = index.search_batch(queries, 10, 48)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for t in range(6):
+        assert_search_equal(got[t], want, "thread %d" % t)
+
+
 def test_host_pointer_batch_api_matches_single_queries(glove):
     """hnsw_search_batch (nq queries) == nq calls of hnsw_search (the reference's one-query API)"""
     index, _, queries = glove
