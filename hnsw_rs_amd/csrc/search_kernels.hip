@@ -733,9 +733,11 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
     if (!stage_query<KIND>(v, qv, yq, lane)) status = HNSW_ERR_NAN_INPUT;
 
     // query values of this lane in registers when the dimension is a compile-time constant
-    constexpr int NQR = (KIND == HNSW_VEC_QUANT8 && DS > 0) ? (4 * (DS / 8) + DS % 8) : 1;
+    // (wide compile-time dimensions keep the query in LDS: 4 d / 8 registers would not fit)
+    constexpr bool QREG = (KIND == HNSW_VEC_QUANT8 && DS > 0 && DS <= 160);
+    constexpr int NQR = QREG ? (4 * (DS / 8) + DS % 8) : 1;
     QRegs<NQR> qreg;
-    if (KIND == HNSW_VEC_QUANT8 && DS > 0) {
+    if (QREG) {
 #pragma unroll
         for (int e = 0; e < NQR; e++) qreg.v[e] = yq[h * nq_half + e];
     }
@@ -763,10 +765,10 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
 #pragma unroll
                     for (int p = 0; p < P; p++) w[p] = src[p];
                 }
-                if (DS > 0)
+                if (QREG)
                     quant_half_sums<(P > 0 ? P : 1), DS>(w, qreg, h, v.nch4, v.rem, acc);
                 else
-                    quant_half_sums<(P > 0 ? P : 1), 0>(w, qlds, h, v.nch4, v.rem, acc);
+                    quant_half_sums<(P > 0 ? P : 1), DS>(w, qlds, h, v.nch4, v.rem, acc);
             }
             // acc.iter().sum(): ((((((a0+a1)+a2)+a3)+a4)+a5)+a6)+a7 with a4..a7 on the odd lane
             const float b0 = pair_swap(acc[0]), b1 = pair_swap(acc[1]), b2 = pair_swap(acc[2]),
@@ -2115,9 +2117,14 @@ int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipSt
     // the configs[1] dimension gets compile-time row loops
     void (*kfn)(const DevView, const InsertArgs, const uint32_t);
     if (v.kind == HNSW_VEC_QUANT8)
-        kfn = v.dim == 100 ? hx_insert_kernel<HNSW_VEC_QUANT8, 100> : hx_insert_kernel<HNSW_VEC_QUANT8, 0>;
+        kfn = v.dim == 100   ? hx_insert_kernel<HNSW_VEC_QUANT8, 100>
+              : v.dim == 128 ? hx_insert_kernel<HNSW_VEC_QUANT8, 128>
+              : v.dim == 768 ? hx_insert_kernel<HNSW_VEC_QUANT8, 768>
+                             : hx_insert_kernel<HNSW_VEC_QUANT8, 0>;
     else
-        kfn = v.dim == 100 ? hx_insert_kernel<HNSW_VEC_F32, 100> : hx_insert_kernel<HNSW_VEC_F32, 0>;
+        kfn = v.dim == 100   ? hx_insert_kernel<HNSW_VEC_F32, 100>
+              : v.dim == 128 ? hx_insert_kernel<HNSW_VEC_F32, 128>
+                             : hx_insert_kernel<HNSW_VEC_F32, 0>;
     const void *kern = reinterpret_cast<const void *>(kfn);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2308,9 +2315,14 @@ int launch_connect(const DevView &v, const ConnectArgs &a, hipStream_t stream) {
     const size_t lds = 2 * 64 * 8 + yq_bytes;
     void (*kfn)(const DevView, const ConnectArgs);
     if (v.kind == HNSW_VEC_QUANT8)
-        kfn = v.dim == 100 ? hx_connect_kernel<HNSW_VEC_QUANT8, 100> : hx_connect_kernel<HNSW_VEC_QUANT8, 0>;
+        kfn = v.dim == 100   ? hx_connect_kernel<HNSW_VEC_QUANT8, 100>
+              : v.dim == 128 ? hx_connect_kernel<HNSW_VEC_QUANT8, 128>
+              : v.dim == 768 ? hx_connect_kernel<HNSW_VEC_QUANT8, 768>
+                             : hx_connect_kernel<HNSW_VEC_QUANT8, 0>;
     else
-        kfn = v.dim == 100 ? hx_connect_kernel<HNSW_VEC_F32, 100> : hx_connect_kernel<HNSW_VEC_F32, 0>;
+        kfn = v.dim == 100   ? hx_connect_kernel<HNSW_VEC_F32, 100>
+              : v.dim == 128 ? hx_connect_kernel<HNSW_VEC_F32, 128>
+                             : hx_connect_kernel<HNSW_VEC_F32, 0>;
     hipLaunchKernelGGL(kfn, dim3(a.count), dim3(64), lds, stream, v, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -2435,7 +2447,8 @@ template <int KIND, int P, int DS>
 static int launch_r(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint32_t slots_log2,
                     hipStream_t stream, uint32_t ef_max) {
     // the inline-rows variant needs one pass to cover a whole layer-0 row
-    constexpr bool CAN_FAT = (KIND == HNSW_VEC_QUANT8 && P > 0);
+    // (block images of rows wider than 5 pieces per half would not leave 4 waves per CU: not built)
+    constexpr bool CAN_FAT = (KIND == HNSW_VEC_QUANT8 && P > 0 && P <= 5);
     if constexpr (CAN_FAT) {
         // 16 rows per wave must be whole 1-KiB DMA pieces: row_stride * 16 % 1024 == 0
         if (v.fat != nullptr && v.S0 == 32 && a.layer_lo == 0 && a.entries == nullptr &&
@@ -2475,6 +2488,8 @@ int launch_search(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint3
     if (v.kind == HNSW_VEC_QUANT8) {
         const uint32_t P = v.half_bytes / 16;
         if (v.dim == 100) return launch_r<HNSW_VEC_QUANT8, 4, 100>(v, a, nblocks, slots_log2, stream, ef_max);
+        if (v.dim == 128 && P == 5) return launch_r<HNSW_VEC_QUANT8, 5, 128>(v, a, nblocks, slots_log2, stream, ef_max);
+        if (v.dim == 768 && P == 25) return launch_r<HNSW_VEC_QUANT8, 25, 768>(v, a, nblocks, slots_log2, stream, ef_max);
         switch (P) {
             case 1: return launch_r<HNSW_VEC_QUANT8, 1, 0>(v, a, nblocks, slots_log2, stream, ef_max);
             case 2: return launch_r<HNSW_VEC_QUANT8, 2, 0>(v, a, nblocks, slots_log2, stream, ef_max);
@@ -2486,6 +2501,8 @@ int launch_search(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint3
     }
     if (v.dim == 100 && v.row_stride == 400)
         return launch_r<HNSW_VEC_F32, 25, 100>(v, a, nblocks, slots_log2, stream, ef_max);
+    if (v.dim == 128 && v.row_stride == 512)
+        return launch_r<HNSW_VEC_F32, 32, 128>(v, a, nblocks, slots_log2, stream, ef_max);
     return launch_r<HNSW_VEC_F32, 0, 0>(v, a, nblocks, slots_log2, stream, ef_max);
 }
 
