@@ -2119,6 +2119,7 @@ int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipSt
     if (v.kind == HNSW_VEC_QUANT8)
         kfn = v.dim == 100   ? hx_insert_kernel<HNSW_VEC_QUANT8, 100>
               : v.dim == 128 ? hx_insert_kernel<HNSW_VEC_QUANT8, 128>
+              : v.dim == 256 ? hx_insert_kernel<HNSW_VEC_QUANT8, 256>
               : v.dim == 768 ? hx_insert_kernel<HNSW_VEC_QUANT8, 768>
                              : hx_insert_kernel<HNSW_VEC_QUANT8, 0>;
     else
@@ -2317,6 +2318,7 @@ int launch_connect(const DevView &v, const ConnectArgs &a, hipStream_t stream) {
     if (v.kind == HNSW_VEC_QUANT8)
         kfn = v.dim == 100   ? hx_connect_kernel<HNSW_VEC_QUANT8, 100>
               : v.dim == 128 ? hx_connect_kernel<HNSW_VEC_QUANT8, 128>
+              : v.dim == 256 ? hx_connect_kernel<HNSW_VEC_QUANT8, 256>
               : v.dim == 768 ? hx_connect_kernel<HNSW_VEC_QUANT8, 768>
                              : hx_connect_kernel<HNSW_VEC_QUANT8, 0>;
     else
@@ -2489,6 +2491,7 @@ int launch_search(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint3
         const uint32_t P = v.half_bytes / 16;
         if (v.dim == 100) return launch_r<HNSW_VEC_QUANT8, 4, 100>(v, a, nblocks, slots_log2, stream, ef_max);
         if (v.dim == 128 && P == 5) return launch_r<HNSW_VEC_QUANT8, 5, 128>(v, a, nblocks, slots_log2, stream, ef_max);
+        if (v.dim == 256 && P == 9) return launch_r<HNSW_VEC_QUANT8, 9, 256>(v, a, nblocks, slots_log2, stream, ef_max);
         if (v.dim == 768 && P == 25) return launch_r<HNSW_VEC_QUANT8, 25, 768>(v, a, nblocks, slots_log2, stream, ef_max);
         switch (P) {
             case 1: return launch_r<HNSW_VEC_QUANT8, 1, 0>(v, a, nblocks, slots_log2, stream, ef_max);
