@@ -47,6 +47,9 @@ f32p = C.POINTER(C.c_float)
 vp = C.c_void_p
 
 # every symbol include/hnsw_mi355x.h declares: name -> (restype, argtypes)
+# int (*hnsw_allgather_fn)(void *ctx, uint64_t bytes_per_rank)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64)
+
 SYMBOLS = {
     "hnsw_last_error": (C.c_char_p, []),
     "hnsw_version": (C.c_char_p, []),
@@ -58,6 +61,9 @@ SYMBOLS = {
     "hnsw_insert_bulk": (C.c_int, [vp, f32p, C.c_uint64, C.c_uint32, C.c_int]),
     "hnsw_insert_bulk_levels": (C.c_int, [vp, f32p, C.c_uint64, C.c_uint32, C.c_int, u8p]),
     "hnsw_insert_bulk_device": (C.c_int, [vp, f32p, C.c_uint64, C.c_uint32, C.c_int, u8p]),
+    "hnsw_sharded_slot_bytes": (C.c_uint64, [vp, C.c_uint32]),
+    "hnsw_insert_bulk_sharded": (C.c_int, [vp, f32p, C.c_uint64, C.c_uint32, C.c_int, u8p, C.c_uint32, C.c_uint32,
+                                           vp, vp, C.c_uint64, ALLGATHER_FN, vp]),
     "hnsw_insert_vec": (C.c_int, [vp, f32p, u32p]),
     "hnsw_insert_vec_level": (C.c_int, [vp, f32p, C.c_int, u32p]),
     "hnsw_import_points": (C.c_int, [vp, f32p, C.c_uint64, u8p]),

@@ -519,8 +519,28 @@ void clamp_rows_to_cap(hx::HostIndex &host, std::vector<uint64_t> *restore) {
     }
 }
 
+// Sharded build (BASELINE configs[4]): every rank holds the full replica and runs phases 2 / 3 on it;
+// the insertion searches of a batch -- the expensive phase -- are split over the ranks, and what they
+// produce travels as edge records through ONE all-gather per batch (the caller's collective, RCCL in
+// production).  The record list carries the whole batch (own rows included, InsertArgs::emit_own), the
+// sort makes its order canonical, phases 2 / 3 are deterministic: the replicas stay identical.
+struct ShardCtx {
+    uint32_t rank, world;
+    unsigned char *d_send, *d_recv;  // one slot / world slots of slot_bytes
+    uint64_t slot_bytes;
+    hnsw_allgather_fn allgather;
+    void *ctx;
+};
+constexpr uint32_t SH_HEADER = 64, SH_FAILCAP = 1024, SH_BCAP = 8192;
+inline uint32_t shard_slot_records(uint32_t m, uint32_t world) {
+    return ((SH_BCAP + world - 1) / world) * m * 4;  // both directions, 2 x slack for upper layers
+}
+inline uint64_t shard_slot_bytes(uint32_t m, uint32_t world) {
+    return ((uint64_t)SH_HEADER + SH_FAILCAP * 4 + (uint64_t)shard_slot_records(m, world) * 12 + 255) & ~255ull;
+}
+
 int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads, int verbose,
-                         const uint8_t *levels) {
+                         const uint8_t *levels, const ShardCtx *sh = nullptr) {
     using hx::NodeID;
     hx::HostIndex &host = *h->host;
     if (nb_threads == 0) nb_threads = 1;
@@ -528,8 +548,13 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         set_error("on-device build supports m <= 32 and ef_construction <= 512");
         return HNSW_ERR_ARG;
     }
-    if (host.len() + n >= (1ull << hx::HX_EDGE_ID_BITS))  // edge records carry 30-bit ids
+    if (host.len() + n >= (1ull << hx::HX_EDGE_ID_BITS)) {  // edge records carry 30-bit ids
+        if (sh) {
+            set_error("sharded build: ids must stay below 2^30");
+            return HNSW_ERR_ARG;
+        }
         return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels);
+    }
     const uint64_t n_before = host.len();
     std::vector<NodeID> ids;
     int rc = host.store_points(rows, n, levels, &ids);
@@ -573,8 +598,14 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     HIP_TRY(hipSetDevice(h->dev.device));
     hx::DevView v = h->dev.view;
     const uint32_t m = (uint32_t)host.params.m, L = host.nb_layers();
-    const uint32_t BMAX = 8192;
-    const uint32_t REQ_CAP = BMAX * m * 2;  // a point has 1 + 1/(m-1) layers on average
+    const uint32_t BMAX = SH_BCAP;
+    // a point has 1 + 1/(m-1) layers on average; sharded: records in both directions
+    const uint32_t W = sh ? sh->world : 1, SLOT_REC = sh ? shard_slot_records(m, W) : 0;
+    const uint32_t REQ_CAP = sh ? W * SLOT_REC : BMAX * m * 2;
+    if (sh && (sh->slot_bytes < shard_slot_bytes(m, W) || sh->rank >= W || !sh->d_send || !sh->d_recv || !sh->allgather)) {
+        set_error("sharded build: exchange buffers too small or bad rank / world");
+        return HNSW_ERR_ARG;
+    }
     const uint32_t REF_CAP = 1u << 20;      // kept-last-edge records of the whole build
     const size_t temp_bytes = hx::sort_temp_bytes(REQ_CAP);
     DevBuf dLevels, dIds, dOutIds, dOutD, dStatus, dCnt, dKeyA, dKeyB, dValA, dValB, dTemp, dRef;
@@ -601,7 +632,9 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
                                           std::min<uint64_t>(BMAX, std::max<uint64_t>(64, connected / 8)));
         const NodeID *batch = &order[pos];
         auto t0 = std::chrono::steady_clock::now();
-        HIP_TRY(hipMemcpy(dIds.p, batch, B * 4, hipMemcpyHostToDevice));
+        // this rank's slice of the batch (everything when not sharded)
+        const size_t s_lo = sh ? B * sh->rank / W : 0, s_hi = sh ? B * (sh->rank + 1) / W : B, nb = s_hi - s_lo;
+        if (nb) HIP_TRY(hipMemcpy(dIds.p, batch + s_lo, nb * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemset(dCnt.p, 0, 8));  // requests, removals
         // ---- phase 1: searches + heuristic, own rows, requests ----
         hx::InsertArgs a{};
@@ -615,17 +648,74 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         a.out_status = dStatus.as<int32_t>();
         a.adj0_mut = h->dev.adj0_mut();
         a.adj_up_mut = h->dev.adj_up_mut();
-        a.req_keys = dKeyA.as<uint64_t>();
-        a.req_vals = dValA.as<uint32_t>();
-        a.req_count = cnt + 0;
-        a.req_cap = REQ_CAP;
-        rc = hx::launch_insert(v, a, (uint32_t)B, nullptr);
-        if (rc != HNSW_OK) return rc;
-        HIP_TRY(hipMemcpy(counts, dCnt.p, 16, hipMemcpyDeviceToHost));  // synchronises
-        HIP_TRY(hipMemcpy(o_st.data(), dStatus.p, B * 4, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < B; i++)
-            if (o_st[i] != HNSW_OK) failed.push_back(batch[i]);  // filed nothing; CPU path after the build
-        const uint32_t nreq = std::min<uint32_t>(counts[0], REQ_CAP);
+        uint32_t nreq = 0;
+        if (!sh) {
+            a.req_keys = dKeyA.as<uint64_t>();
+            a.req_vals = dValA.as<uint32_t>();
+            a.req_count = cnt + 0;
+            a.req_cap = REQ_CAP;
+            rc = hx::launch_insert(v, a, (uint32_t)nb, nullptr);
+            if (rc != HNSW_OK) return rc;
+            HIP_TRY(hipMemcpy(counts, dCnt.p, 16, hipMemcpyDeviceToHost));  // synchronises
+            HIP_TRY(hipMemcpy(o_st.data(), dStatus.p, nb * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < nb; i++)
+                if (o_st[i] != HNSW_OK) failed.push_back(batch[i]);  // filed nothing; CPU path after the build
+            nreq = std::min<uint32_t>(counts[0], REQ_CAP);
+        } else {
+            // the slot: [count, nfail, ...64 B][failed ids][keys][vals]
+            unsigned char *slot = sh->d_send;
+            uint32_t *hdr = reinterpret_cast<uint32_t *>(slot);
+            uint32_t *fail_ids = reinterpret_cast<uint32_t *>(slot + SH_HEADER);
+            const size_t o_keys = SH_HEADER + SH_FAILCAP * 4, o_vals = o_keys + (size_t)SLOT_REC * 8;
+            HIP_TRY(hipMemset(slot, 0, SH_HEADER));
+            a.req_keys = reinterpret_cast<uint64_t *>(slot + o_keys);
+            a.req_vals = reinterpret_cast<uint32_t *>(slot + o_vals);
+            a.req_count = hdr;
+            a.req_cap = SLOT_REC;
+            a.emit_own = 1;
+            rc = hx::launch_insert(v, a, (uint32_t)nb, nullptr);
+            if (rc != HNSW_OK) return rc;
+            if (nb) HIP_TRY(hipMemcpy(o_st.data(), dStatus.p, nb * 4, hipMemcpyDeviceToHost));  // synchronises
+            std::vector<uint32_t> myfail;
+            for (size_t i = 0; i < nb; i++)
+                if (o_st[i] != HNSW_OK) myfail.push_back(batch[s_lo + i]);
+            if (myfail.size() > SH_FAILCAP) {
+                set_error("sharded build: %zu points of one batch failed on the device", myfail.size());
+                return HNSW_ERR_OVERFLOW;
+            }
+            const uint32_t nf = (uint32_t)myfail.size();
+            HIP_TRY(hipMemcpy(hdr + 1, &nf, 4, hipMemcpyHostToDevice));
+            if (nf) HIP_TRY(hipMemcpy(fail_ids, myfail.data(), nf * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipDeviceSynchronize());
+            // ---- the one exchange of the batch ----
+            rc = sh->allgather(sh->ctx, sh->slot_bytes);
+            if (rc != 0) {
+                set_error("sharded build: the all-gather callback failed (%d)", rc);
+                return HNSW_ERR_RCCL;
+            }
+            // concatenate the slots' records; every rank sees the same list
+            for (uint32_t r = 0; r < W; r++) {
+                const unsigned char *rs = sh->d_recv + (size_t)r * sh->slot_bytes;
+                uint32_t rh[2];
+                HIP_TRY(hipMemcpy(rh, rs, 8, hipMemcpyDeviceToHost));
+                if (rh[0] > SLOT_REC || rh[1] > SH_FAILCAP || nreq + rh[0] > REQ_CAP) {
+                    set_error("sharded build: malformed slot from rank %u", r);
+                    return HNSW_ERR_ARG;
+                }
+                if (rh[1]) {
+                    std::vector<uint32_t> f(rh[1]);
+                    HIP_TRY(hipMemcpy(f.data(), rs + SH_HEADER, rh[1] * 4, hipMemcpyDeviceToHost));
+                    failed.insert(failed.end(), f.begin(), f.end());
+                }
+                if (rh[0]) {
+                    HIP_TRY(hipMemcpyAsync(dKeyA.as<uint64_t>() + nreq, rs + o_keys, (size_t)rh[0] * 8,
+                                           hipMemcpyDeviceToDevice, nullptr));
+                    HIP_TRY(hipMemcpyAsync(dValA.as<uint32_t>() + nreq, rs + o_vals, (size_t)rh[0] * 4,
+                                           hipMemcpyDeviceToDevice, nullptr));
+                }
+                nreq += rh[0];
+            }
+        }
         auto t1 = std::chrono::steady_clock::now();
         // ---- phase 2: group by target row (radix sort), append / prune ----
         rc = hx::sort_edge_pairs(dTemp.p, temp_bytes, dKeyA.as<uint64_t>(), dKeyB.as<uint64_t>(),
@@ -810,6 +900,18 @@ int hnsw_insert_bulk_levels(hnsw_index *h, const float *rows, uint64_t n, uint32
     if (h->gpu_build == 2) return gpu_insert_bulk_full(h, rows, n, nb_threads, verbose, levels);
     if (h->gpu_build) return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels);
     return h->host->insert_bulk(rows, n, nb_threads, verbose != 0, levels);
+}
+uint64_t hnsw_sharded_slot_bytes(const hnsw_index *h, uint32_t world) {
+    if (!h || world == 0) return 0;
+    return shard_slot_bytes((uint32_t)h->host->params.m, world);
+}
+int hnsw_insert_bulk_sharded(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads, int verbose,
+                             const uint8_t *levels, uint32_t rank, uint32_t world, void *d_send, void *d_recv,
+                             uint64_t slot_bytes, hnsw_allgather_fn allgather, void *ctx) {
+    if (!h || !rows || world == 0 || rank >= world) return HNSW_ERR_ARG;
+    ShardCtx sh{rank, world, static_cast<unsigned char *>(d_send), static_cast<unsigned char *>(d_recv), slot_bytes,
+                allgather, ctx};
+    return gpu_insert_bulk_full(h, rows, n, nb_threads, verbose, levels, &sh);
 }
 int hnsw_insert_bulk_device(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads,
                             int verbose, const uint8_t *levels) {

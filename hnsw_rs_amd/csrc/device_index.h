@@ -91,6 +91,7 @@ struct InsertArgs {
     uint32_t *req_vals;         // bits of d(source, target)
     uint32_t *req_count;
     uint32_t req_cap;
+    uint32_t emit_own;          // 1: no own-row writes, records in both directions (sharded build)
 };
 
 // An edge record of the on-device connect, made to be radix-sorted: records of one adjacency row

@@ -2066,6 +2066,10 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
             const uint32_t id = (uint32_t)lane < m ? o_ids[(size_t)l * m + lane] : HX_EMPTY_SLOT;
             total += (uint32_t)__popcll(__ballot(id != HX_EMPTY_SLOT));
         }
+        // emit_own (sharded build): the point's own rows travel as records too -- (layer, p <- n) next
+        // to (layer, n <- p) -- so that the record list alone carries the whole batch to every replica
+        const uint32_t per_edge = a.emit_own ? 2u : 1u;
+        total *= per_edge;
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(a.req_count, total);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -2074,16 +2078,24 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
         } else {
             for (uint32_t l = 0; l <= level; l++) {
                 const uint32_t S = l == 0 ? v.S0 : v.S1;
-                uint32_t *row = l == 0 ? a.adj0_mut + (size_t)p * S
-                                       : a.adj_up_mut + ((size_t)v.upper_base[p] + l - 1) * S;
                 const uint32_t id = (uint32_t)lane < m ? o_ids[(size_t)l * m + lane] : HX_EMPTY_SLOT;
-                if ((uint32_t)lane < S) row[lane] = id;
-                const u64 vm = __ballot(id != HX_EMPTY_SLOT);  // a prefix of the lanes
-                if (id != HX_EMPTY_SLOT) {
-                    a.req_keys[base + lane] = hx_edge_key(l, id, p);
-                    a.req_vals[base + lane] = __builtin_bit_cast(uint32_t, o_d[(size_t)l * m + lane]);
+                if (!a.emit_own) {
+                    uint32_t *row = l == 0 ? a.adj0_mut + (size_t)p * S
+                                           : a.adj_up_mut + ((size_t)v.upper_base[p] + l - 1) * S;
+                    if ((uint32_t)lane < S) row[lane] = id;
                 }
-                base += (uint32_t)__popcll(vm);
+                const u64 vm = __ballot(id != HX_EMPTY_SLOT);  // a prefix of the lanes
+                const uint32_t cnt = (uint32_t)__popcll(vm);
+                if (id != HX_EMPTY_SLOT) {
+                    const uint32_t db = __builtin_bit_cast(uint32_t, o_d[(size_t)l * m + lane]);
+                    a.req_keys[base + lane] = hx_edge_key(l, id, p);
+                    a.req_vals[base + lane] = db;
+                    if (a.emit_own) {
+                        a.req_keys[base + cnt + lane] = hx_edge_key(l, p, id);
+                        a.req_vals[base + cnt + lane] = db;
+                    }
+                }
+                base += cnt * per_edge;
             }
         }
     }

@@ -169,6 +169,50 @@ class HNSW:
                                               1 if verbose else 0, _p(lv, _u8p)))
         return self
 
+    def insert_bulk_sharded(self, vectors, nb_threads, verbose, levels=None, group=None, device=None):
+        """The on-device build sharded over the ranks of a torch.distributed group (BASELINE configs[4]):
+        every rank passes the same vectors / levels and ends with an identical replica; the insertion
+        searches of each batch are split over the ranks and their edge records are exchanged with one
+        all-gather per batch (RCCL when the group's backend is nccl; staged through the host for gloo)."""
+        import torch
+        import torch.distributed as dist
+        from ._lib import ALLGATHER_FN
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        slot = int(self._L.hnsw_sharded_slot_bytes(self._h, world))
+        send = torch.zeros(slot, dtype=torch.uint8, device=dev)
+        recv = torch.zeros(world * slot, dtype=torch.uint8, device=dev)
+        on_device = dist.get_backend(group) == "nccl"
+        failure = []
+
+        def allgather(_ctx, nbytes):
+            try:
+                if nbytes != slot:
+                    return 1
+                if on_device:
+                    dist.all_gather_into_tensor(recv, send, group=group)
+                    torch.cuda.synchronize(dev)
+                else:  # gloo: CPU tensors
+                    parts = [torch.empty(slot, dtype=torch.uint8) for _ in range(world)]
+                    dist.all_gather(parts, send.cpu(), group=group)
+                    recv.copy_(torch.cat(parts))
+                    torch.cuda.synchronize(dev)
+                return 0
+            except Exception as e:  # never unwind through the C frames
+                failure.append(e)
+                return 2
+
+        cb = ALLGATHER_FN(allgather)
+        rows = self._rows(vectors)
+        lv = None if levels is None else np.ascontiguousarray(levels, dtype=np.uint8)
+        rc = self._L.hnsw_insert_bulk_sharded(self._h, _p(rows, _f32p), rows.shape[0], nb_threads,
+                                              1 if verbose else 0, _p(lv, _u8p), rank, world,
+                                              C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), slot, cb, None)
+        if failure:
+            raise failure[0]
+        check(rc)
+        return self
+
     def insert_vec(self, vector, level=None):
         """HNSW::insert_vec(&mut self, &Vec<f32>) -> Result<NodeID, String>"""
         v = self._rows([vector] if not isinstance(vector, np.ndarray) else vector.reshape(1, -1))

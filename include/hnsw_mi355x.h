@@ -119,6 +119,19 @@ int hnsw_insert_bulk_levels(hnsw_index *h, const float *rows, uint64_t n, uint32
  * hybrid form (GPU searches, connect / prune on nb_threads host threads with the reference's locks). */
 int hnsw_insert_bulk_device(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads,
                             int verbose, const uint8_t *levels);
+/* The on-device build sharded over the GPUs of a node (BASELINE configs[4]): every rank calls this with
+ * the SAME rows / levels on its own replica.  The insertion searches of each batch are split over the
+ * ranks; what they produce travels as edge records through one all-gather per batch, after which every
+ * rank applies the same records to its replica (connect / prune / remove are deterministic, so the
+ * replicas stay identical).  The collective is the caller's: d_send (one slot) and d_recv (world slots)
+ * are device buffers of hnsw_sharded_slot_bytes() per slot, and `allgather(ctx, bytes_per_rank)` must
+ * all-gather d_send into d_recv across the ranks and return 0 once d_recv is complete (RCCL through
+ * torch.distributed in hnsw_rs_amd/hnsw.py).  The library has synchronised the device before it calls. */
+typedef int (*hnsw_allgather_fn)(void *ctx, uint64_t bytes_per_rank);
+uint64_t hnsw_sharded_slot_bytes(const hnsw_index *h, uint32_t world);
+int hnsw_insert_bulk_sharded(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads, int verbose,
+                             const uint8_t *levels, uint32_t rank, uint32_t world, void *d_send, void *d_recv,
+                             uint64_t slot_bytes, hnsw_allgather_fn allgather, void *ctx);
 /* HNSW::insert_vec(&mut self, &Vec<f32>) -> Result<NodeID, String>, template.rs:165-173 */
 int hnsw_insert_vec(hnsw_index *h, const float *v, uint32_t *out_id);
 int hnsw_insert_vec_level(hnsw_index *h, const float *v, int level /* < 0: draw */, uint32_t *out_id);

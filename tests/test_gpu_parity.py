@@ -443,3 +443,65 @@ def test_device_connect_other_shapes(kind, m, d):
     # and the search on it is still the reference's search
     orc = oracle_from_product(idx, vs, lv)
     assert_search_equal(idx.search_batch(qs, 10, 40), orc.search_batch(qs, 10, 40, nthreads=8), "device-connect")
+
+
+# ---------------------------------------------------------------------------------------------------
+# sharded on-device build (BASELINE configs[4]): two ranks, gloo rendezvous, both on this one GPU --
+# the exchange is the only thing that differs from an 8-GPU run (RCCL there, host-staged gloo here)
+# ---------------------------------------------------------------------------------------------------
+def _sharded_build_worker(rank, world, port, outdir):
+    import os
+    import sys
+    import torch.distributed as dist
+    from tests.conftest import ROOT
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import hnsw_rs_amd as HH
+    n, d, m = 20000, 100, 16
+    vs = HH.synth_rows(0, 0x5EED0001, 0, n, d)
+    lv = HH.draw_levels(m, n)
+    idx = HH.HNSW.new(m, 32, d)
+    idx.insert_bulk_sharded(vs, 4, False, levels=lv)
+    out = {}
+    for layer in idx.iter_layers():
+        ids, offs, nbrs = layer.csr()
+        # rows as sorted sets: the order inside a row is not part of the graph
+        rows = [np.sort(nbrs[int(offs[k]):int(offs[k + 1])]) for k in range(len(ids))]
+        out["ids%d" % layer.level] = ids
+        out["offs%d" % layer.level] = offs
+        out["nbrs%d" % layer.level] = np.concatenate(rows) if rows else nbrs
+    qs = HH.synth_rows(0, 0x5EED0002, 0, 128, d)
+    truth, _ = idx.brute_force(qs, 10)
+    got, _, _, _ = idx.search_batch(qs, 10, 64)
+    out["recall"] = np.array([sum(len(set(a) & set(b)) for a, b in zip(got.tolist(), truth.tolist())) / 1280.0])
+    out["compliant"] = np.array([1 if idx.assert_param_compliance() else 0])
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_device_build_two_ranks(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sharded_build_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert sorted(r0.files) == sorted(r1.files)
+    for k in r0.files:  # identical replicas, edge for edge
+        assert np.array_equal(r0[k], r1[k]), k
+    assert r0["recall"][0] > 0.97 and r0["compliant"][0] == 1
+    # and the same graph as the single-GPU on-device build of the same input: the sharding only
+    # changes who runs which search, and the searches of a batch do not depend on each other
+    n, d, m = 20000, 100, 16
+    vs = H.synth_rows(0, 0x5EED0001, 0, n, d)
+    one = H.HNSW.new(m, 32, d).insert_bulk_device(vs, 4, False, levels=H.draw_levels(m, n))
+    for layer in one.iter_layers():
+        ids, offs, nbrs = layer.csr()
+        rows = [np.sort(nbrs[int(offs[k]):int(offs[k + 1])]) for k in range(len(ids))]
+        assert np.array_equal(r0["offs%d" % layer.level], offs)
+        assert np.array_equal(r0["nbrs%d" % layer.level], np.concatenate(rows))
