@@ -73,6 +73,7 @@ struct SearchArgs {
     uint32_t *out_counts;        // nq or null
     hnsw_query_stats *out_stats; // nq
     unsigned long long *dbg;     // diagnostic builds only (HX_STAMPS): nq x 6 cycle sums, else null
+    uint32_t flags;              // bit 0: one row per pass (disables the two-row loops; HNSW_MI355X_ONE_ROW=1)
 };
 
 // one batch of the on-device build: insertion searches for point_ids[0..n) (search_kernels.hip)

@@ -1049,7 +1049,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
             continue;
         }
 
-        if (KIND == HNSW_VEC_F32 && !FAT && layer == 0 && S <= 32) {
+        if (KIND == HNSW_VEC_F32 && !FAT && layer == 0 && S <= 32 && !(a.flags & 1u)) {
             // ---- layer 0, one lane per neighbour, rows of at most 32 slots: TWO rows per pass.
             // Lanes 0..31 take the row of the candidate c being expanded, lanes 32..63 the row of the
             // runner-up p (the smallest unexpanded entry once c is marked).  Both adjacency rows and
@@ -2492,9 +2492,12 @@ static int launch_r(const DevView &v, const SearchArgs &a, uint32_t nblocks, uin
     return HNSW_ERR_ARG;
 }
 
-int launch_search(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint32_t slots_log2,
+int launch_search(const DevView &v, const SearchArgs &a_in, uint32_t nblocks, uint32_t slots_log2,
                   hipStream_t stream) {
     if (nblocks == 0) return HNSW_OK;
+    SearchArgs a = a_in;
+    static const bool one_row = getenv("HNSW_MI355X_ONE_ROW") && atoi(getenv("HNSW_MI355X_ONE_ROW")) != 0;
+    if (one_row) a.flags |= 1u;
     uint32_t ef_max = std::max(1u, a.ef_bottom);
     if (a.layer_hi > a.layer_lo) ef_max = std::max(ef_max, a.ef_upper);
     if (a.entries) ef_max = std::max(ef_max, a.n_entry);
