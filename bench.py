@@ -222,6 +222,33 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
         out["at_configured_efSearch_64"] = {"queries_per_s_per_gpu": round(B / ms64 * 1e3, 1),
                                             "ms_per_step": round(ms64, 5),
                                             "recall_at_%d" % n: recall_by_ef[64]}
+    # Not the metric: the same 1024-query launches with several batches in flight (one stream each).
+    # A 1024-query launch puts one wave on every SIMD; independent batches share the SIMDs and hide each
+    # other's memory waits, which is what a server with concurrent requests sees.
+    try:
+        from hnsw_rs_amd.distributed import make_device_search
+        S_CONC = 4
+        streams = [torch.cuda.Stream(device=c.dev) for _ in range(S_CONC)]
+        searchers = [make_device_search(index, n, ef, B, c.dev) for _ in range(S_CONC)]
+        qs = [c.dQ[b][:B].contiguous() for b in range(nqb)]
+        steps = 80
+
+        def burst(k):
+            for i in range(k):
+                with torch.cuda.stream(streams[i % S_CONC]):
+                    searchers[i % S_CONC](qs[i % nqb])
+        burst(8)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        burst(steps)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - tc
+        out["concurrent_batches"] = {
+            "streams": S_CONC, "batch": B, "efSearch": ef, "queries_per_s_per_gpu": round(B * steps / wall, 1),
+            "hbm_frac_algorithmic": round(bytes_per_launch * steps / wall / 1e9 / HBM_PEAK_GBS, 5),
+            "note": "secondary; the metric's value times one batch at a time"}
+    except Exception as e:  # a secondary figure must never cost the bench line
+        log("concurrent-batches measurement skipped: %s" % e)
     if not a.no_cpu_baseline:
         from oracle import oracle_py as O
         t2 = time.time()
