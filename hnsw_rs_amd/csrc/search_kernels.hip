@@ -381,7 +381,46 @@ __device__ __forceinline__ float dist_any_dim(const DevView &v, uint32_t id, boo
         if (active) {
             const uint4 *src = reinterpret_cast<const uint4 *>(v.rows + (size_t)id * v.row_stride);
             const uint32_t np = v.row_stride >> 4, d = v.dim;
-            for (uint32_t p0 = 0; p0 < np; p0 += 8) {
+            // bulk: whole pairs of 16-piece stages, two register buffers, the next stage in flight
+            // while the current one is summed (one exposed round trip per 512 B instead of per 128 B);
+            // only pieces that lie entirely inside the row's d floats take this path
+            constexpr uint32_t CH = 16;
+            const uint32_t full_pieces = d >> 2;                      // pieces without padding floats
+            const uint32_t pairs = full_pieces / (2 * CH);
+            uint32_t p_done = 0;
+            if (pairs > 0) {
+                uint4 a[CH], b[CH];
+                auto fetch_at = [&](uint4 (&w)[CH], const uint4 *p) __attribute__((always_inline)) {
+#pragma unroll
+                    for (uint32_t i = 0; i < CH; i++) w[i] = p[i];
+                };
+                auto consume_at = [&](const uint4 (&w)[CH], const float *y) __attribute__((always_inline)) {
+#pragma unroll
+                    for (uint32_t i = 0; i < CH; i++) {
+                        const uint32_t dw[4] = {w[i].x, w[i].y, w[i].z, w[i].w};
+#pragma unroll
+                        for (int j = 0; j < 4; j += 2) {
+                            const f32x2 x = {__builtin_bit_cast(float, dw[j]), __builtin_bit_cast(float, dw[j + 1])};
+                            const f32x2 yy = {y[4 * i + j], y[4 * i + j + 1]};
+                            const f32x2 t = x - yy;
+                            const f32x2 t2 = t * t;
+                            s += t2.x;
+                            s += t2.y;
+                        }
+                    }
+                };
+                fetch_at(a, src);
+#pragma unroll 1
+                for (uint32_t pr = 0; pr < pairs; pr++) {
+                    const uint32_t st = 2 * pr;
+                    fetch_at(b, src + (st + 1) * CH);
+                    consume_at(a, yq + 4 * st * CH);
+                    if (pr + 1 < pairs) fetch_at(a, src + (st + 2) * CH);
+                    consume_at(b, yq + 4 * (st + 1) * CH);
+                }
+                p_done = pairs * 2 * CH;
+            }
+            for (uint32_t p0 = p_done; p0 < np; p0 += 8) {
                 uint4 w[8];
 #pragma unroll
                 for (int p = 0; p < 8; p++)
@@ -468,6 +507,89 @@ __device__ __forceinline__ float f32_row_sum(const uint4 (&w)[P], const float *y
                 s += t * t;
             }
         }
+    }
+    return s;
+}
+
+// Wide f32 rows (d > 192): the same single chain, with the row streamed through two register buffers
+// of CH 16-byte pieces each.  The stage loop has a compile-time trip count and is fully unrolled, so
+// the code is straight-line: the loads of stage s + 1 are in flight while stage s is summed and the
+// compiler's s_waitcnt counts are exact (a rolled loop drains them at its header).
+template <int DS, int CH, bool ROLLED>
+__device__ __forceinline__ float f32_row_sum_staged(const uint4 *src, const float *yq) {
+    constexpr int NP = (DS + 3) / 4, NST = (NP + CH - 1) / CH;
+    static_assert(!ROLLED || (NP % (2 * CH) == 0), "the rolled form needs whole stage pairs");
+    uint4 a[CH], b[CH];
+    float s = 0.0f;
+    auto fetch = [&](uint4 (&w)[CH], int st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < CH; p++)
+            if (st * CH + p < NP) w[p] = src[st * CH + p];
+    };
+    auto consume = [&](const uint4 (&w)[CH], int st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < CH; p++) {
+            if (st * CH + p >= NP) continue;
+            const uint32_t dw[4] = {w[p].x, w[p].y, w[p].z, w[p].w};
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const int e = 4 * (st * CH + p) + j;
+                if (e >= DS) continue;
+                if (e + 1 < DS) {
+                    const f32x2 x = {__builtin_bit_cast(float, dw[j]), __builtin_bit_cast(float, dw[j + 1])};
+                    const f32x2 y = {yq[e], yq[e + 1]};
+                    const f32x2 t = x - y;
+                    const f32x2 t2 = t * t;
+                    s += t2.x;
+                    s += t2.y;
+                } else {
+                    const float t = __builtin_bit_cast(float, dw[j]) - yq[e];
+                    s += t * t;
+                }
+            }
+        }
+    };
+    if constexpr (ROLLED) {
+        // very wide rows: the unrolled form outgrows the instruction cache (d = 768: 3.9 ms against
+        // 1.9 ms for the plain loop), so the stage pairs stay a loop -- one exposed round trip per
+        // 2 CH pieces instead of one per 8
+        auto fetch_at = [&](uint4 (&w)[CH], const uint4 *p) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < CH; i++) w[i] = p[i];
+        };
+        auto consume_at = [&](const uint4 (&w)[CH], const float *y) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const uint32_t dw[4] = {w[i].x, w[i].y, w[i].z, w[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const f32x2 x = {__builtin_bit_cast(float, dw[j]), __builtin_bit_cast(float, dw[j + 1])};
+                    const f32x2 yy = {y[4 * i + j], y[4 * i + j + 1]};
+                    const f32x2 t = x - yy;
+                    const f32x2 t2 = t * t;
+                    s += t2.x;
+                    s += t2.y;
+                }
+            }
+        };
+        static_assert(DS % 4 == 0, "whole pieces");
+        fetch_at(a, src);
+#pragma unroll 1
+        for (int st = 0; st < NST; st += 2) {
+            fetch_at(b, src + (st + 1) * CH);
+            consume_at(a, yq + 4 * st * CH);
+            if (st + 2 < NST) fetch_at(a, src + (st + 2) * CH);
+            consume_at(b, yq + 4 * (st + 1) * CH);
+        }
+        return s;
+    }
+    fetch(a, 0);
+#pragma unroll
+    for (int st = 0; st < NST; st += 2) {
+        if (st + 1 < NST) fetch(b, st + 1);
+        consume(a, st);
+        if (st + 2 < NST) fetch(a, st + 2);
+        if (st + 1 < NST) consume(b, st + 1);
     }
     return s;
 }
@@ -787,10 +909,14 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
             float sm = 0.0f;
             if (active) {
                 const uint4 *src = reinterpret_cast<const uint4 *>(v.rows + (size_t)id * v.row_stride);
-                uint4 w[P > 0 ? P : 1];
+                if constexpr (P > 48) {
+                    sm = f32_row_sum_staged<(DS > 0 ? DS : 1), 16, (P > 96)>(src, yq);
+                } else {
+                    uint4 w[P > 0 ? P : 1];
 #pragma unroll
-                for (int p = 0; p < P; p++) w[p] = src[p];
-                sm = f32_row_sum<(P > 0 ? P : 1), (DS > 0 ? DS : 1)>(w, yq);
+                    for (int p = 0; p < P; p++) w[p] = src[p];
+                    sm = f32_row_sum<(P > 0 ? P : 1), (DS > 0 ? DS : 1)>(w, yq);
+                }
             }
             dist = __builtin_sqrtf(sm);
         } else {
@@ -1996,12 +2122,19 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
             if (ns >= m || cursor >= n_c) continue;  // nothing left to decide
             const uint32_t sid = (uint32_t)sk_sel;
             stage_row<KIND>(v, sid, yqe, lane);
+            // (a rolled loop over the list registers with static selects: one copy of the distance
+            // code instead of R x LPC, and the list stays in registers)
+#pragma unroll 1
+            for (int rr = 0; rr < R; rr++) {
+                u64 mine = KEY_INVALID;
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const uint32_t idx = 64u * r + lane;
-                const bool open = idx >= cursor && idx < n_c && (wl.L[r] & KEY_EXPANDED) == 0;
+                for (int r = 0; r < R; r++)
+                    if (r == rr) mine = wl.L[r];
+                const uint32_t idx = 64u * rr + lane;
+                const bool open = idx >= cursor && idx < n_c && (mine & KEY_EXPANDED) == 0;
                 if (__ballot(open) == 0) continue;
-                const uint32_t my_id = (uint32_t)wl.L[r], my_db = (uint32_t)(wl.L[r] >> 32);
+                const uint32_t my_id = (uint32_t)mine, my_db = (uint32_t)(mine >> 32);
+                bool mark = false;
 #pragma unroll
                 for (int half = 0; half < LPC; half++) {
                     const int src = half * CHUNK + cslot;  // the lane that owns this pass's candidate
@@ -2018,9 +2151,12 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
                         rej = sk < ck;
                     }
                     const u64 rm = __ballot(rej);  // bit LPC * cslot of the pass <-> owner lane src
-                    const int mine = lane - half * CHUNK;
-                    if (mine >= 0 && mine < CHUNK && ((rm >> (LPC * mine)) & 1)) wl.L[r] |= KEY_EXPANDED;
+                    const int own = lane - half * CHUNK;
+                    if (own >= 0 && own < CHUNK && ((rm >> (LPC * own)) & 1)) mark = true;
                 }
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    if (r == rr && mark) wl.L[r] |= KEY_EXPANDED;
             }
             if (__ballot(status != HNSW_OK)) status = HNSW_ERR_NAN_INPUT;
         }
@@ -2521,6 +2657,10 @@ int launch_search(const DevView &v, const SearchArgs &a_in, uint32_t nblocks, ui
         return launch_r<HNSW_VEC_F32, 25, 100>(v, a, nblocks, slots_log2, stream, ef_max);
     if (v.dim == 128 && v.row_stride == 512)
         return launch_r<HNSW_VEC_F32, 32, 128>(v, a, nblocks, slots_log2, stream, ef_max);
+    if (v.dim == 256 && v.row_stride == 1024)
+        return launch_r<HNSW_VEC_F32, 64, 256>(v, a, nblocks, slots_log2, stream, ef_max);
+    if (v.dim == 768 && v.row_stride == 3072)
+        return launch_r<HNSW_VEC_F32, 192, 768>(v, a, nblocks, slots_log2, stream, ef_max);
     return launch_r<HNSW_VEC_F32, 0, 0>(v, a, nblocks, slots_log2, stream, ef_max);
 }
 
