@@ -910,7 +910,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
             if (active) {
                 const uint4 *src = reinterpret_cast<const uint4 *>(v.rows + (size_t)id * v.row_stride);
                 if constexpr (P > 48) {
-                    sm = f32_row_sum_staged<(DS > 0 ? DS : 1), 16, (P > 96)>(src, yq);
+                    sm = f32_row_sum_staged<(DS > 0 ? DS : 1), 16, true>(src, yq);
                 } else {
                     uint4 w[P > 0 ? P : 1];
 #pragma unroll
