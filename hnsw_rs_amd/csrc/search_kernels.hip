@@ -623,6 +623,7 @@ __device__ __forceinline__ float dist_build(const DevView &v, uint32_t id, bool 
             uint4 w[P];
 #pragma unroll
             for (int p = 0; p < P; p++) w[p] = src[p];
+            __builtin_amdgcn_sched_barrier(0);  // every piece requested before the arithmetic
             const QLds q{yq + h * (v.half_bytes - 8)};
             quant_half_sums<P, DS>(w, q, h, v.nch4, v.rem, acc);
         }
@@ -646,6 +647,7 @@ __device__ __forceinline__ float dist_build(const DevView &v, uint32_t id, bool 
             uint4 w[P];
 #pragma unroll
             for (int p = 0; p < P; p++) w[p] = src[p];
+            __builtin_amdgcn_sched_barrier(0);
             sm = f32_row_sum<P, DS>(w, yq);
         }
         return __builtin_sqrtf(sm);
@@ -886,6 +888,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                 } else {
 #pragma unroll
                     for (int p = 0; p < P; p++) w[p] = src[p];
+                    __builtin_amdgcn_sched_barrier(0);  // every piece requested before the arithmetic
                 }
                 if (QREG)
                     quant_half_sums<(P > 0 ? P : 1), DS>(w, qreg, h, v.nch4, v.rem, acc);
@@ -915,6 +918,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                     uint4 w[P > 0 ? P : 1];
 #pragma unroll
                     for (int p = 0; p < P; p++) w[p] = src[p];
+                    __builtin_amdgcn_sched_barrier(0);  // every piece requested before the chain starts
                     sm = f32_row_sum<(P > 0 ? P : 1), (DS > 0 ? DS : 1)>(w, yq);
                 }
             }
