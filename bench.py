@@ -59,6 +59,8 @@ def parse():
     p.add_argument("--batch", type=int, default=1024)
     p.add_argument("--kind", choices=["f32", "quant8"], default="f32")
     p.add_argument("--no-secondary", action="store_true", help="skip the other vector kind")
+    p.add_argument("--no-concurrent", action="store_true",
+                   help="skip the secondary several-batches-in-flight figure (profiling passes: keeps the kernel trace to the timed launches)")
     p.add_argument("--recipe", type=int, default=0, help="0 = A (low intrinsic dim), 1 = B (isotropic)")
     p.add_argument("--query-batches", type=int, default=10, help="distinct batches cycled through")
     p.add_argument("--build-threads", type=int, default=0)
@@ -226,6 +228,8 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
     # A 1024-query launch puts one wave on every SIMD; independent batches share the SIMDs and hide each
     # other's memory waits, which is what a server with concurrent requests sees.
     try:
+        if a.no_concurrent:
+            raise RuntimeError("--no-concurrent")
         from hnsw_rs_amd.distributed import make_device_search
         S_CONC = 4
         streams = [torch.cuda.Stream(device=c.dev) for _ in range(S_CONC)]
