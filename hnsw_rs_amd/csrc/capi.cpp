@@ -268,7 +268,7 @@ int gpu_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_th
     }
     const uint64_t n_before = host.len();
     std::vector<NodeID> ids;
-    int rc = host.store_points(rows, n, levels, &ids);
+    int rc = host.store_points(rows, n, levels, &ids, nb_threads);
     if (rc != HNSW_OK) return rc;
     host.prepare_build();
     // insertion order of the reference: layers top-down, ids ascending inside a level (template.rs:403-416)
@@ -557,7 +557,7 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     }
     const uint64_t n_before = host.len();
     std::vector<NodeID> ids;
-    int rc = host.store_points(rows, n, levels, &ids);
+    int rc = host.store_points(rows, n, levels, &ids, nb_threads);
     if (rc != HNSW_OK) return rc;
     host.prepare_build();
     std::vector<NodeID> order;

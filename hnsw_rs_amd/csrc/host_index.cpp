@@ -608,7 +608,7 @@ int HostIndex::connect_point(NodeID point_id, const std::vector<std::vector<Dist
 
 // HNSW::store_points, template.rs:269-293
 int HostIndex::store_points(const float *rows, uint64_t n, const uint8_t *levels_in,
-                            std::vector<NodeID> *ids_out) {
+                            std::vector<NodeID> *ids_out, uint32_t nb_threads) {
     if (n == 0) {
         set_error("no vectors given");
         return HNSW_ERR_EMPTY;
@@ -630,15 +630,32 @@ int HostIndex::store_points(const float *rows, uint64_t n, const uint8_t *levels
         new_codes.resize((size_t)n * dim);
         new_mins.resize(n);
         new_deltas.resize(n);
-        for (uint64_t i = 0; i < n; i++) {
-            int rc = quantize(rows + i * dim, dim, &new_mins[i], &new_deltas[i],
-                              &new_codes[(size_t)i * dim]);
-            if (rc == HNSW_OK && !std::isfinite(new_deltas[i])) rc = HNSW_ERR_NAN_INPUT;
-            if (rc != HNSW_OK) {
-                set_error("row %llu: NaN / non-finite range cannot be quantised",
-                          (unsigned long long)i);
-                return rc;
+        // rows are independent: quantise on nb_threads threads, report the first bad row
+        std::atomic<uint64_t> bad{UINT64_MAX};
+        auto work = [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t i = lo; i < hi && bad.load(std::memory_order_relaxed) == UINT64_MAX; i++) {
+                int rc = quantize(rows + i * dim, dim, &new_mins[i], &new_deltas[i],
+                                  &new_codes[(size_t)i * dim]);
+                if (rc == HNSW_OK && !std::isfinite(new_deltas[i])) rc = HNSW_ERR_NAN_INPUT;
+                if (rc != HNSW_OK) {
+                    uint64_t cur = bad.load();
+                    while (i < cur && !bad.compare_exchange_weak(cur, i)) {
+                    }
+                    return;
+                }
             }
+        };
+        const unsigned nt = (unsigned)std::min<uint64_t>(std::max(1u, nb_threads), std::max<uint64_t>(1, n / 4096));
+        if (nt <= 1) {
+            work(0, n);
+        } else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; t++) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+            for (auto &t : th) t.join();
+        }
+        if (bad.load() != UINT64_MAX) {
+            set_error("row %llu: NaN / non-finite range cannot be quantised", (unsigned long long)bad.load());
+            return HNSW_ERR_NAN_INPUT;
         }
     } else {
         for (uint64_t i = 0; i < n * dim; i++)
@@ -673,7 +690,7 @@ int HostIndex::insert_bulk(const float *rows, uint64_t n, uint32_t nb_threads, b
                            const uint8_t *levels_in) {
     if (nb_threads == 0) nb_threads = 1;
     std::vector<NodeID> ids;
-    int rc = store_points(rows, n, levels_in, &ids);
+    int rc = store_points(rows, n, levels_in, &ids, nb_threads);
     if (rc != HNSW_OK) return rc;
     const NodeID first = ids.front();  // stored ids are contiguous
     ensure_locks();

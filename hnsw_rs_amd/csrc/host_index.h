@@ -102,7 +102,7 @@ class HostIndex {
 
     // ---- build (hnsw/src/template.rs) ----
     int store_points(const float *rows, uint64_t n, const uint8_t *levels_in,
-                     std::vector<NodeID> *ids_out);
+                     std::vector<NodeID> *ids_out, uint32_t nb_threads = 1);
     int insert(NodeID point_id, Inserter &ins);
     // second half of insert (template.rs:185-187): make_connections, prune_connections,
     // make_pruned_connections for the results held by `ins`
