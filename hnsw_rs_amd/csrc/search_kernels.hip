@@ -1946,8 +1946,9 @@ hx_search2_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2
 // way is judged by recall, not by identity with the sequential build.  Deviations, all documented
 // in DESIGN.md: the heuristic's candidate set is capped at the 512 nearest (the reference keeps
 // all of selected ∪ their neighbours); the un-popped heuristic candidates do not leak into the
-// next layer's frontier.  The edges themselves are applied on the host with the
-// reference's make_connections / prune_connections / make_pruned_connections.
+// next layer's frontier.  The edges themselves are applied by hx_connect_kernel /
+// hx_remove_kernel below from the edge records this kernel files (or, in the hybrid build, on the host
+// with the reference's make_connections / prune_connections / make_pruned_connections).
 // =============================================================================================
 template <int KIND, int DS>
 __global__ void __launch_bounds__(64)
