@@ -674,10 +674,13 @@ struct WaveList {
         u64 smask = __ballot(surv);
         if (smask == 0) return;
         const uint32_t m = (uint32_t)__popcll(smask);
-        if (m <= 4) {
+        if (m <= (R == 1 ? 4u : 0u)) {
             // few survivors (the usual case once the list is full): insert them one at a time by
             // shifting the tail of the register-resident list one lane to the right (DPP
-            // wave_shr:1, no LDS round trip).  Insertion order is irrelevant (N2).
+            // wave_shr:1, no LDS round trip).  Insertion order is irrelevant (N2).  Only for one-
+            // register lists: with R > 1 every insert shifts R registers with a carry, and the
+            // rank-scatter below is cheaper even for a single survivor (f32 efSearch 68: 0.266 ->
+            // 0.255 ms; SQ counters had shown +33 % VALU instructions per query for R = 2 vs R = 1).
             u64 it = smask;
             while (it) {
                 const int j = __ffsll((long long)it) - 1;
