@@ -67,6 +67,25 @@ def test_nan_rows_are_rejected():
         assert e.value.code == _lib.ERR_NAN_INPUT
 
 
+def test_threaded_quantisation_reports_the_first_bad_row_and_leaves_the_index_untouched():
+    """rows are quantised on nb_threads threads; a bad row anywhere rejects the whole call"""
+    v = rand_vectors(30000, 8, 4)
+    v[21000, 2] = np.nan
+    v[9000, 1] = np.nan
+    index = H.HNSW.new(8, None, 8)
+    with pytest.raises(H.HnswError) as e:
+        index.insert_bulk(v, 8, False)
+    assert e.value.code == _lib.ERR_NAN_INPUT and "row 9000" in str(e.value)
+    assert index.len() == 0
+    # and the threaded path stores what the single-threaded one stores
+    good = rand_vectors(20000, 8, 5)
+    a = H.HNSW.new(8, None, 8)
+    a.import_points(good, np.zeros(len(good), np.uint8))
+    b = H.HNSW.new(8, None, 8).insert_bulk(good[:64], 8, False)  # small: below the threading threshold
+    for i in (0, 17, 63):
+        assert np.array_equal(a.get_point(i).get_vals(), b.get_point(i).get_vals())
+
+
 @pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
 @pytest.mark.parametrize("n,d,m,seed", [(100, 10, 12, 1), (700, 16, 4, 2), (1500, 33, 8, 3)])
 def test_single_thread_build_equals_oracle(kind, n, d, m, seed):
