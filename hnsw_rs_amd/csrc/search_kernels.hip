@@ -313,6 +313,54 @@ __device__ __forceinline__ void stage_row(const DevView &v, uint32_t id, float *
 }
 
 // ---------------------------------------------------------------------------------------------
+// QUANT8, any dimension: the pieces of a half row that hold nothing but chunk elements, without
+// per-element predicates, in stages of CH 16-byte pieces through two register buffers (the next
+// stage in flight while the current one is summed).  Starts at piece `first` >= 1 (piece 0 carries the
+// header); returns the number of pieces consumed (a multiple of CH).  Element e of the half sits at
+// byte 8 + e.
+// ---------------------------------------------------------------------------------------------
+template <int CH>
+__device__ __forceinline__ uint32_t quant_bulk_stages(const uint4 *src, const float *yh, float delta, float mn,
+                                                      uint32_t first, uint32_t n_pure, float (&acc)[4]) {
+    const uint32_t nst = n_pure / CH;
+    if (nst == 0) return 0;
+    uint4 a[CH], b[CH];
+    auto fetch_at = [&](uint4 (&w)[CH], uint32_t st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CH; i++) w[i] = src[first + st * CH + i];
+    };
+    auto consume_at = [&](const uint4 (&w)[CH], uint32_t st) __attribute__((always_inline)) {
+        const float *y = yh + 16 * (first + st * CH) - 8;  // query value of the stage's first element
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const uint32_t dw[4] = {w[i].x, w[i].y, w[i].z, w[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+#pragma unroll
+                for (int k = 0; k < 4; k += 2) {
+                    const f32x2 c = {(float)((dw[j] >> (8 * k)) & 0xFFu), (float)((dw[j] >> (8 * (k + 1))) & 0xFFu)};
+                    const f32x2 x = c * delta + mn;
+                    const f32x2 yy = {y[16 * i + 4 * j + k], y[16 * i + 4 * j + k + 1]};
+                    const f32x2 t = x - yy;
+                    const f32x2 t2 = t * t;
+                    acc[k] += t2.x;
+                    acc[k + 1] += t2.y;
+                }
+            }
+        }
+    };
+    fetch_at(a, 0);
+#pragma unroll 1
+    for (uint32_t st = 0; st < nst; st += 2) {
+        if (st + 1 < nst) fetch_at(b, st + 1);
+        consume_at(a, st);
+        if (st + 2 < nst) fetch_at(a, st + 2);
+        if (st + 1 < nst) consume_at(b, st + 1);
+    }
+    return nst * CH;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Distance of one stored point to the staged query for ANY dimension (runtime loops): used by
 // the test-seam and brute-force kernels, and by the search kernel when no specialised variant
 // fits.  QUANT8: valid on the even lane of the pair; F32: per lane.
@@ -330,36 +378,54 @@ __device__ __forceinline__ float dist_any_dim(const DevView &v, uint32_t id, boo
             const uint4 w0 = src[0];
             const float mn = __builtin_bit_cast(float, w0.x);
             const float delta = __builtin_bit_cast(float, w0.y);
-            // groups of 4 pieces so that 64 B per lane are in flight
-            for (uint32_t p0 = 0; p0 < np; p0 += 4) {
-                uint4 w[4];
+            // Pieces [p_lo, p_hi) through the predicated element loop, 4 pieces (64 B) per group.
+            auto consume_pred = [&](uint32_t p_lo, uint32_t p_hi) __attribute__((always_inline)) {
+                for (uint32_t p0 = p_lo; p0 < p_hi; p0 += 4) {
+                    uint4 w[4];
 #pragma unroll
-                for (int p = 0; p < 4; p++)
-                    w[p] = (p0 + p < np) ? src[p0 + p] : make_uint4(0, 0, 0, 0);
+                    for (int p = 0; p < 4; p++)
+                        w[p] = (p0 + p < p_hi) ? src[p0 + p] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    const uint32_t dw[4] = {w[p].x, w[p].y, w[p].z, w[p].w};
+                    for (int p = 0; p < 4; p++) {
+                        if (p0 + p >= p_hi) continue;  // wave-uniform: a piece outside the range costs nothing
+                        const uint32_t dw[4] = {w[p].x, w[p].y, w[p].z, w[p].w};
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
+                        for (int j = 0; j < 4; j++) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int e = 16 * (int)(p0 + p) + 4 * j + k - 8;
-                            const float x = ((float)((dw[j] >> (8 * k)) & 0xFFu) * delta) + mn;
-                            const bool chunk = e >= 0 && (uint32_t)e < v.nch4;
-                            const bool tail =
-                                e >= 0 && !chunk && (uint32_t)e < v.nch4 + v.rem && h == 0;
-                            const float y = (chunk || tail) ? yh[e] : 0.0f;
-                            const float t = x - y;
-                            const float t2 = t * t;
-                            if (k == 0) {
-                                acc[0] += (chunk || tail) ? t2 : 0.0f;
-                            } else {
-                                acc[k] += chunk ? t2 : 0.0f;
-                                acc[0] += tail ? t2 : 0.0f;
+                            for (int k = 0; k < 4; k++) {
+                                const int e = 16 * (int)(p0 + p) + 4 * j + k - 8;
+                                const float x = ((float)((dw[j] >> (8 * k)) & 0xFFu) * delta) + mn;
+                                const bool chunk = e >= 0 && (uint32_t)e < v.nch4;
+                                const bool tail = e >= 0 && !chunk &&
+                                                  (uint32_t)e < v.nch4 + v.rem && h == 0;
+                                const float y = (chunk || tail) ? yh[e] : 0.0f;
+                                const float t = x - y;
+                                const float t2 = t * t;
+                                if (k == 0) {
+                                    acc[0] += (chunk || tail) ? t2 : 0.0f;
+                                } else {
+                                    acc[k] += chunk ? t2 : 0.0f;
+                                    acc[0] += tail ? t2 : 0.0f;
+                                }
                             }
                         }
                     }
                 }
+            };
+            // Pieces 1 .. that hold nothing but chunk elements go through the predicate-free stages
+            // (quant_bulk_stages); piece 0 (header) before, the remainder after -- every running sum
+            // still sees its elements in ascending order.
+            const uint32_t n_pure = v.nch4 >= 24 ? (v.nch4 - 8) / 16 : 0;  // pieces [1, 1 + n_pure)
+            if (n_pure < 4) {
+                consume_pred(0, np);
+            } else {
+                consume_pred(0, 1);
+                // widest stages first, then narrower ones over what is left of the pure pieces
+                uint32_t used = 0;
+                if (n_pure >= 16) used += quant_bulk_stages<8>(src, yh, delta, mn, 1, n_pure, acc);
+                used += quant_bulk_stages<4>(src, yh, delta, mn, 1 + used, n_pure - used, acc);
+                used += quant_bulk_stages<1>(src, yh, delta, mn, 1 + used, n_pure - used, acc);
+                consume_pred(1 + used, np);
             }
         }
         // acc.iter().sum(): ((((((a0+a1)+a2)+a3)+a4)+a5)+a6)+a7 with a4..a7 on the odd lane

@@ -81,7 +81,7 @@ def test_search_layer_seam(glove):
 
 
 @pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
-@pytest.mark.parametrize("d", [1, 7, 10, 16, 33, 50, 64, 100, 128, 200, 256])
+@pytest.mark.parametrize("d", [1, 7, 10, 16, 33, 50, 64, 100, 128, 200, 256, 300, 600, 1030])
 def test_dimensions_and_vector_kinds(kind, d):
     n, m = 600, 8
     vs = rand_vectors(n, d, 100 + d) * np.float32(2.0) - np.float32(0.5)
