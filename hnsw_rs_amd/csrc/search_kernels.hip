@@ -2688,7 +2688,19 @@ static int launch_r(const DevView &v, const SearchArgs &a, uint32_t nblocks, uin
     // than a quarter of the CU's LDS, so that 1024 waves fit the chip in one round
     const uint32_t r_list = ef_max <= 64 ? 1 : ef_max <= 128 ? 2 : ef_max <= 256 ? 4 : 8;
     const size_t fat_lds = (4ull << slots_log2) + 64ull * r_list * 8 + 2ull * 1024 * (P > 0 ? P : 1) + 1024;
-    if (CAN_FAT && v.fat != nullptr && v.S0 == 32 && a.layer_lo == 0 && fat_lds <= 40 * 1024) {
+    // ... and only while the launch is small enough to be latency-bound: with more than four waves per CU
+    // the compact layout wins (measured, 1M x 100d quant8, efSearch 68: 2048 queries 0.359 ms inline
+    // rows vs 0.256 ms compact; 32768 queries 8.4 vs 10.6 M q/s) -- the block images halve the
+    // resident waves and every slot of a block is read whether it is needed or not
+    static const uint32_t n_cu = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        return (uint32_t)cus;
+    }();
+    if (CAN_FAT && v.fat != nullptr && v.S0 == 32 && a.layer_lo == 0 && fat_lds <= 40 * 1024 &&
+        nblocks <= 4 * n_cu) {
         if (ef_max <= 64) return launch_one<KIND, P, DS, 1, CAN_FAT>(v, a, nblocks, slots_log2, stream);
         if (ef_max <= 128) return launch_one<KIND, P, DS, 2, CAN_FAT>(v, a, nblocks, slots_log2, stream);
         if (ef_max <= 256) return launch_one<KIND, P, DS, 4, CAN_FAT>(v, a, nblocks, slots_log2, stream);
