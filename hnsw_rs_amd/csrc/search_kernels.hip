@@ -1009,6 +1009,8 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
     };
 
     // ---- one pass over up to CHUNK neighbour ids (one per lane group) ----
+    // entries the visited table holds (exact: the overflow check adds the row's worst case before a pass)
+    uint32_t n_vis = 0;
     auto process = [&](uint32_t id, bool valid, bool visit, uint32_t ef_l, bool hidden_loads = false) {
         bool fresh = valid;
         if (visit) {
@@ -1018,6 +1020,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
             fresh = f;
         }
         const u64 fm = __ballot(fresh && h == 0);
+        if (visit) n_vis += (uint32_t)__popcll(fm);
         if (fm == 0) return;
         n_dist += (uint32_t)__popcll(fm);
         u64 key = eval_key(id, fresh, hidden_loads);
@@ -1025,7 +1028,6 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
         wl.merge(key, ef_l, perm, lane);
     };
 
-    uint32_t n_vis = 0;
     if (status == HNSW_OK) {
         // ---- entry set: {ep} (template.rs:316-319) or the caller's (search_layer seam) ----
         const uint32_t n_entry = a.entries ? a.n_entry : 1;
@@ -1164,11 +1166,11 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                         status = HNSW_ERR_OVERFLOW;
                         break;
                     }
-                    n_vis += cnt;
                     bool f = false;
                     if (valid && h == 0) f = visited_insert(htab, hmask, slots_log2, nb);
                     const bool fresh = (pair_swap_i(f ? 1 : 0) | (f ? 1 : 0)) != 0;
                     const u64 fm = __ballot(fresh && h == 0);
+                    n_vis += (uint32_t)__popcll(fm);  // what the table really holds
                     STAMP(t2);
 #ifdef HX_STAMPS
                     if (dbg_hit)
@@ -1238,7 +1240,6 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                             status = HNSW_ERR_OVERFLOW;
                             break;
                         }
-                        n_vis += ocnt;
                         process(onb, ov, true, ef_l, true);
                         if (status != HNSW_OK) break;
                     }
@@ -1299,9 +1300,9 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                     status = HNSW_ERR_OVERFLOW;
                     break;
                 }
-                n_vis += cnt_c;
                 bool want = false;
                 if (valid && !upper) want = visited_insert(htab, hmask, slots_log2, nb);
+                n_vis += (uint32_t)__popcll(__ballot(want && !upper));  // what the table really holds
                 // (the look-up runs after the inserts of this pass: what c just claimed is skipped)
                 wave_fence();
                 if (valid && upper && spec_ok) want = !visited_contains(htab, hmask, slots_log2, nb);
@@ -1327,7 +1328,6 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                             status = HNSW_ERR_OVERFLOW;
                             break;
                         }
-                        n_vis += ocnt;
                         process(onb, ov, true, ef_l);
                         if (status != HNSW_OK) break;
                     }
@@ -1353,11 +1353,11 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                     status = HNSW_ERR_OVERFLOW;
                     break;
                 }
-                n_vis += cnt_p;
                 // every valid neighbour of p goes through the filter now: one that c's commit inserted
                 // meanwhile is dropped, one that was skipped above was in the set already
                 bool fresh = false;
                 if (valid && upper) fresh = visited_insert(htab, hmask, slots_log2, nb);
+                n_vis += (uint32_t)__popcll(__ballot(fresh));
                 n_dist += (uint32_t)__popcll(__ballot(fresh));
                 if (__ballot(fresh && nan)) {
                     status = HNSW_ERR_NAN_INPUT;
@@ -1409,7 +1409,6 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                     status = HNSW_ERR_OVERFLOW;
                     break;
                 }
-                n_vis += cnt;
                 process(nb, valid, true, ef_l);
                 if (status != HNSW_OK) break;
             }
@@ -1425,7 +1424,6 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                         status = HNSW_ERR_OVERFLOW;
                         break;
                     }
-                    n_vis += cnt;
                     process(nb, valid, true, ef_l);
                     if (status != HNSW_OK) break;
                 }
@@ -2072,7 +2070,9 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
             if (LPC == 2) f = (pair_swap_i(f ? 1 : 0) | (f ? 1 : 0)) != 0;
             fresh = f;
         }
-        if (__ballot(fresh && first) == 0) return;
+        const u64 fm = __ballot(fresh && first);
+        if (visit) n_vis += (uint32_t)__popcll(fm);  // what the table really holds
+        if (fm == 0) return;
         const float dist = dist_build<KIND, DS>(v, id, fresh, h, yq);
         u64 key = KEY_INVALID;
         bool nan = false;
@@ -2121,7 +2121,6 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
                     status = HNSW_ERR_OVERFLOW;
                     break;
                 }
-                n_vis += cnt;
                 process(nb, valid, true, ef_l, new_flag);
             }
         }
@@ -2583,17 +2582,18 @@ int launch_scatter_rows(uint32_t *dst, uint32_t S, const uint32_t *d_row_index, 
 // launchers
 // ---------------------------------------------------------------------------------------------
 
-// Visited-table size for a search with list size ef on rows of up to s0 neighbours.  The table must
-// hold every id whose distance is computed in one layer: measured means are 18.5 ef at ef <= 128
-// falling to 13 ef at ef = 256 for 32-slot rows (1M..10M points); the limit (75 % of the slots) is
-// kept >= 1.5 x that.  Too small is safe (status OVERFLOW; the host-pointer API retries with the
-// next size), too large costs occupancy: 64 KiB tables leave 2 waves per CU, i.e. a 1024-query
-// launch no longer fits the chip in one round.
+// Visited-table size for a search with list size ef on rows of up to s0 neighbours.  The table holds
+// every id whose distance is computed in one layer; measured on 10240 queries of the 1M x 100d index
+// (32-slot rows): efSearch 64 mean 1190 / max 1769, 96: 1593 / 2235, 128: 1966 / 2810, 288: 3593 / 5599
+// (scripts/nvis_probe.py).  The limit (75 % of the slots) stays >= 1.1 x the observed maximum plus one
+// row.  Too small is safe (status OVERFLOW; the host-pointer API retries with the next size), too
+// large costs occupancy: 64 KiB tables leave 2 waves per CU, i.e. a 1024-query launch no longer fits
+// the chip in one round.
 uint32_t default_slots_log2(uint32_t ef, uint32_t s0) {
     const uint64_t e = (uint64_t)ef * std::max(s0, 8u) / 32u;  // ef in units of 32-slot rows
-    if (e <= 96) return 12;   // 4096 slots, 16 KiB: limit 3072
-    if (e <= 288) return 13;  // 8192 slots, 32 KiB: limit 6144
-    if (e <= 640) return 14;  // 64 KiB
+    if (e <= 112) return 12;  // 4096 slots, 16 KiB: limit 3072
+    if (e <= 256) return 13;  // 8192 slots, 32 KiB: limit 6144
+    if (e <= 576) return 14;  // 64 KiB: limit 12288
     return 15;                // 128 KiB
 }
 uint32_t default_slots_log2(uint32_t ef) { return default_slots_log2(ef, 32); }
