@@ -82,12 +82,18 @@ def main():
     p.add_argument("--n", type=int, default=10)
     p.add_argument("--threads", type=int, default=1)
     p.add_argument("--kind", choices=["quant8", "f32"], default="quant8")
+    p.add_argument("--device-build", action="store_true",
+                   help="build the index on the GPU (hnsw_insert_bulk_device) instead of the reference's CPU algorithm")
     a = p.parse_args()
     _, store = load_glove_array(a.lim, a.store, True)
     _, queries = load_glove_array(0, a.queries, False)
     kind = VEC_QUANT8 if a.kind == "quant8" else VEC_F32
     t = time.time()
-    index = HNSW.new(a.m, None, store.shape[1], kind).insert_bulk(store, a.threads, True)
+    index = HNSW.new(a.m, None, store.shape[1], kind)
+    if a.device_build:
+        index.insert_bulk_device(store, max(1, a.threads), True)
+    else:
+        index.insert_bulk(store, a.threads, True)
     print("built %d points in %.2fs" % (index.len(), time.time() - t))
     print("Final accuracy was %.4f" % recall_at(index, queries, a.n, a.ef))
     for layer in index.iter_layers():
