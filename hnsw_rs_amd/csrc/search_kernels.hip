@@ -918,6 +918,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
     int32_t status = HNSW_OK;
 #ifdef HX_STAMPS
     unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dbg_mid = 0;
     const unsigned long long t_begin = __builtin_readcyclecounter();
 #endif
 
@@ -988,6 +989,10 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
 #pragma unroll
                     for (int p = 0; p < P; p++) w[p] = src[p];
                     __builtin_amdgcn_sched_barrier(0);  // every piece requested before the chain starts
+#ifdef HX_STAMPS
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    dbg_mid = __builtin_readcyclecounter();
+#endif
                     sm = f32_row_sum<(P > 0 ? P : 1), (DS > 0 ? DS : 1)>(w, yq);
                 }
             }
@@ -1263,6 +1268,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
             int cpos = wl.first_unexpanded(lane);  // carried: the pick after a merge is the next c
             while (status == HNSW_OK) {
                 if (cpos < 0) break;
+                STAMP(f0);
                 uint32_t cid = 0;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
@@ -1282,6 +1288,12 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                 const uint32_t slot = (uint32_t)lane & 31u;
                 uint32_t nb = HX_EMPTY_SLOT;
                 if (slot < S && (!upper || ppos >= 0)) nb = v.adj0[(size_t)(upper ? pid : cid) * S + slot];
+#ifdef HX_STAMPS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                STAMP(f1);
+                STAMP_ADD(0, f0, f1);
+                dbg_acc[7]++;
+#endif
                 const bool is_ptr = nb != HX_EMPTY_SLOT && (nb & HX_OVF_FLAG);
                 const bool valid = nb != HX_EMPTY_SLOT && !is_ptr;
                 const u64 pm = __ballot(is_ptr);
@@ -1307,8 +1319,16 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                 wave_fence();
                 if (valid && upper && spec_ok) want = !visited_contains(htab, hmask, slots_log2, nb);
                 n_dist += (uint32_t)__popcll(__ballot(want && !upper));
+                STAMP(f2);
+                STAMP_ADD(1, f1, f2);
+#ifdef HX_STAMPS
+                dbg_mid = f2;
+#endif
                 float dist = 0.0f;
                 if (__ballot(want)) dist = eval_dist(nb, want, false);
+                STAMP(f3);
+                STAMP_ADD(2, f2, dbg_mid);
+                STAMP_ADD(3, dbg_mid, f3);
                 const bool nan = want && dist != dist;
                 if (__ballot(nan && !upper)) {
                     status = HNSW_ERR_NAN_INPUT;
@@ -1334,6 +1354,8 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                     if (status != HNSW_OK) break;
                 }
                 // ---- is p the next candidate?  then commit it from the registers
+                STAMP(f4);
+                STAMP_ADD(5, f3, f4);
                 const int npos = wl.first_unexpanded(lane);
                 cpos = npos;
                 if (npos < 0) break;
@@ -1365,6 +1387,8 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                 }
                 wl.merge((fresh && upper) ? key : KEY_INVALID, ef_l, perm, lane);
                 cpos = wl.first_unexpanded(lane);
+                STAMP(f5);
+                STAMP_ADD(6, f4, f5);
             }
             continue;
         }
@@ -1526,6 +1550,7 @@ hx_search2_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2
     int32_t status = HNSW_OK;
 #ifdef HX_STAMPS
     unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dbg_mid = 0;
     const unsigned long long t_begin = __builtin_readcyclecounter();
 #endif
 
