@@ -157,6 +157,10 @@ uint32_t adj_stride(uint64_t cap, uint32_t min_slots);
 // hash table size (LDS), 0 = choose from ef.  Returns HNSW_OK or HNSW_ERR_ARG / HNSW_ERR_HIP.
 int launch_search(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint32_t slots_log2,
                   hipStream_t stream);
+// the latency-critical form of the same search (search_lean.hip): whole ann_by_vector descents over
+// f32 rows; launch_search routes to it when it applies
+bool lean_applicable(const DevView &v, const SearchArgs &a, uint32_t ef_max);
+int launch_lean(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint32_t slots_log2, hipStream_t stream);
 uint32_t default_slots_log2(uint32_t ef);
 uint32_t default_slots_log2(uint32_t ef, uint32_t s0);
 uint32_t max_slots_log2(uint32_t ef);

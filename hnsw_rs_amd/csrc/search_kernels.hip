@@ -2749,6 +2749,7 @@ int launch_search(const DevView &v, const SearchArgs &a_in, uint32_t nblocks, ui
     if (a.layer_hi > a.layer_lo) ef_max = std::max(ef_max, a.ef_upper);
     if (a.entries) ef_max = std::max(ef_max, a.n_entry);
     if (slots_log2 == 0) slots_log2 = default_slots_log2(ef_max, v.S0);
+    if (lean_applicable(v, a, ef_max)) return launch_lean(v, a, nblocks, slots_log2, stream);
     if (v.kind == HNSW_VEC_QUANT8) {
         const uint32_t P = v.half_bytes / 16;
         if (v.dim == 100) return launch_r<HNSW_VEC_QUANT8, 4, 100>(v, a, nblocks, slots_log2, stream, ef_max);

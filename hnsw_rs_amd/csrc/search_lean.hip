@@ -1,0 +1,674 @@
+// search_lean.hip -- the latency-critical form of the search hot path for gfx950 (MI355X, CDNA4):
+// HNSW::ann_by_vector (hnsw/src/template.rs:306-335) over FullVec rows (vectors/src/full.rs:23-29)
+// for the launch sizes where a query's own dependent chain, not the memory system, sets the time
+// (a 1024-query batch is one wave per SIMD; measured in round 2 with in-kernel cycle stamps: the
+// generic kernel of search_kernels.hip spent 2.9 k of its 10 k cycles per pass in the distance chain
+// because the compiler fetched every query value through its own LDS round trip with the address
+// spilled to a VGPR lane, 1.6 k in the visited filter's nested divergent loops, and 22 % of the whole
+// query in the handful of upper-layer expansions, each three dependent round trips).
+//
+// Same algorithm, same results, same counters as hx_search_kernel (the parity tests run both):
+//   - one 64-lane wave per query; `selected` + `candidates` (results.rs:26-33) are ONE sorted list of
+//     <= ef keys (dist_bits << 32 | id, bit 63 = expanded), searcher.rs:35-94 is "expand the smallest
+//     unexpanded entry until none is left";
+//   - layer 0 evaluates TWO adjacency rows per pass: lanes 0..31 the candidate c, lanes 32..63 the
+//     runner-up p, which is committed from registers when it is still next after c's merge.
+// What is different:
+//   - the query lives in VGPRs (100 registers at d = 100): the chain is v_pk_add / v_pk_mul / v_add
+//     on registers, nothing else;
+//   - the visited filter is one straight-line round (bucket read, compare, one ds_cmpst) for the whole
+//     wave -- c's lanes insert, p's lanes only look -- with a loop only for the lanes that lost a slot
+//     or met a full bucket;
+//   - the list is interleaved (entry i = lane i / R, register i % R), so an insertion is a one-lane DPP
+//     shift without a carry between registers; one or two survivors are shift-inserted, larger batches
+//     take the rank + LDS scatter;
+//   - the upper layers (ef = 1, searcher.rs:23-103 degenerates to a greedy walk) keep just the best
+//     key, and the next node's adjacency base (upper_base) is fetched together with the vector rows of
+//     the neighbours, so an expansion is two dependent round trips instead of three.
+//
+// Float fidelity: -ffp-contract=off; the sum is FullVec's single left-to-right chain; sqrt is the
+// correctly rounded one.
+
+#include <cstdlib>
+
+#include "device_index.h"
+
+namespace hx {
+namespace {
+
+typedef unsigned long long u64;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr u64 LK_INVALID = ~0ull;
+constexpr u64 LK_MASK = 0x7FFFFFFFFFFFFFFFull;
+constexpr u64 LK_EXPANDED = 1ull << 63;
+
+struct LeanArgs {
+    const float *rows;           // N x DS floats
+    const uint32_t *adj0;        // N x S0
+    const uint32_t *adj_up;      // rows of S1
+    const uint32_t *upper_base;  // N
+    const uint32_t *ovf_off, *ovf_nbrs;
+    const float *Q;
+    const uint32_t *qsel;
+    uint32_t *out_ids;
+    float *out_dists;
+    uint32_t *out_counts;
+    hnsw_query_stats *out_stats;
+    uint32_t n_points, ep, nb_layers, S0, S1, ef, n, slots_log2;
+};
+
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+__device__ __forceinline__ u64 rdlane64(u64 v, uint32_t l) {
+    return ((u64)rdlane((uint32_t)(v >> 32), l) << 32) | rdlane((uint32_t)v, l);
+}
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_or_max(uint32_t x) {  // lanes without a source keep 0xFFFFFFFF
+    return (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, CTRL, 0xF, 0xF, false);
+}
+// minimum over the wave (wave-uniform result)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, dpp_or_max<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = min(v, dpp_or_max<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = min(v, dpp_or_max<0x141>(v));  // row_half_mirror
+    v = min(v, dpp_or_max<0x140>(v));  // row_mirror: every lane holds its row's minimum
+    return min(min(rdlane(v, 0), rdlane(v, 16)), min(rdlane(v, 32), rdlane(v, 48)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// visited set (IntSet::insert, results.rs:101-103): open addressing over buckets of four slots
+// ---------------------------------------------------------------------------------------------
+struct Visited {
+    uint32_t *tab;
+    uint32_t bshift, bmask;  // bucket = (id * K) >> bshift; bmask = buckets - 1
+
+    __device__ __forceinline__ uint32_t home(uint32_t id) const { return (id * 0x9E3779B1u) >> bshift; }
+
+    // One straight-line round for the whole wave.  Every lane reads its home bucket; `found` tells
+    // whether the id is in it.  Lanes with ins == true try to claim the first empty slot.  Returns
+    // true for the lanes that inserted their id; lanes that could not finish (slot lost to another
+    // lane of this round, or bucket full) come back in `again` with `b` set to the bucket to look at.
+    __device__ __forceinline__ bool round(uint32_t id, bool ins, uint32_t &b, bool &found, bool &again) const {
+        const uint4 bk = *reinterpret_cast<const uint4 *>(tab + 4 * b);
+        found = (bk.x == id) | (bk.y == id) | (bk.z == id) | (bk.w == id);
+        const int j = bk.x == HX_EMPTY_SLOT ? 0 : bk.y == HX_EMPTY_SLOT ? 1 : bk.z == HX_EMPTY_SLOT ? 2
+                      : bk.w == HX_EMPTY_SLOT ? 3 : 4;
+        const bool claim = ins & !found & (j < 4);
+        uint32_t old = 0;
+        if (claim) old = atomicCAS(tab + 4 * b + j, HX_EMPTY_SLOT, id);
+        const bool won = claim & (old == HX_EMPTY_SLOT);
+        again = ins & !found & !won;
+        if (ins & !found & (j == 4)) b = (b + 1) & bmask;  // full: the next bucket; a lost slot: same bucket again
+        return won;
+    }
+    // exact insert of the lanes with ins == true (ids of one call are distinct); true = was absent
+    __device__ __forceinline__ bool insert(uint32_t id, bool ins) const {
+        uint32_t b = home(id);
+        bool found, again;
+        bool fresh = round(id, ins, b, found, again);
+        while (__ballot(again)) {
+            bool f2, a2 = false;
+            bool w = false;
+            if (again) w = round(id, true, b, f2, a2);
+            fresh |= w;
+            again = again & a2;
+        }
+        return fresh;
+    }
+    __device__ __forceinline__ void clear(uint32_t nslots, int lane) const {
+        for (uint32_t s = lane; s < (nslots >> 2); s += 64)
+            reinterpret_cast<uint4 *>(tab)[s] = make_uint4(HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT);
+        lds_fence();
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// the sorted list, interleaved over the wave: entry i is register i % R of lane i / R
+// ---------------------------------------------------------------------------------------------
+template <int R>
+struct Lst {
+    u64 L[R];
+    uint32_t n_cur;  // wave-uniform
+    u64 last_key;    // key (flag dropped) of entry ef - 1 when the list is full, else LK_INVALID
+
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int r = 0; r < R; r++) L[r] = LK_INVALID;
+        n_cur = 0;
+        last_key = LK_INVALID;
+    }
+    // index of the smallest entry not expanded yet, -1 if none (invalid entries have bit 63 set)
+    __device__ __forceinline__ int first_unexp() const {
+        uint32_t pos = 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const u64 U = __ballot((int32_t)(uint32_t)(L[r] >> 32) >= 0);
+            const uint32_t i = U ? (uint32_t)(R * (__ffsll((long long)U) - 1) + r) : 0xFFFFFFFFu;
+            pos = min(pos, i);
+        }
+        return (int)pos;
+    }
+    // the two smallest unexpanded entries
+    __device__ __forceinline__ void first_two(int &a, int &b) const {
+        u64 U[R];
+        uint32_t pa = 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            U[r] = __ballot((int32_t)(uint32_t)(L[r] >> 32) >= 0);
+            const uint32_t i = U[r] ? (uint32_t)(R * (__ffsll((long long)U[r]) - 1) + r) : 0xFFFFFFFFu;
+            pa = min(pa, i);
+        }
+        uint32_t pb = 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            u64 V = U[r];
+            if (pa != 0xFFFFFFFFu && (pa % R) == (uint32_t)r) V &= ~(1ull << (pa / R));
+            const uint32_t i = V ? (uint32_t)(R * (__ffsll((long long)V) - 1) + r) : 0xFFFFFFFFu;
+            pb = min(pb, i);
+        }
+        a = (int)pa;
+        b = (int)pb;
+    }
+    __device__ __forceinline__ uint32_t id_at(uint32_t pos) const {
+        uint32_t v = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t t = rdlane((uint32_t)L[r], pos / R);
+            if ((pos % R) == (uint32_t)r) v = t;
+        }
+        return v;
+    }
+    __device__ __forceinline__ u64 key_at(uint32_t pos) const {
+        u64 v = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const u64 t = rdlane64(L[r], pos / R);
+            if ((pos % R) == (uint32_t)r) v = t;
+        }
+        return v;
+    }
+    __device__ __forceinline__ void mark(uint32_t pos, int lane) {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if ((pos % R) == (uint32_t)r && (uint32_t)lane == pos / R) L[r] |= LK_EXPANDED;
+    }
+    __device__ __forceinline__ void refresh_last(uint32_t ef) {
+        last_key = n_cur >= ef ? (key_at(ef - 1) & LK_MASK) : LK_INVALID;
+    }
+
+    // Merge the wave's keys (LK_INVALID = none) into the list, keeping the ef smallest: the streaming
+    // top-ef of searcher.rs:74-94 applied to a whole batch (order-independent).
+    __device__ __forceinline__ void merge(u64 key, uint32_t ef, u64 *perm, int lane) {
+        const bool surv = key < last_key;  // last_key is LK_INVALID while the list is not full
+        const u64 smask = __ballot(surv);
+        if (smask == 0) return;
+        const uint32_t m = (uint32_t)__popcll(smask);
+        if (m <= 2) {
+            u64 it = smask;
+            while (it) {
+                const uint32_t j = (uint32_t)__ffsll((long long)it) - 1;
+                it &= it - 1;
+                const u64 e = rdlane64(key, j);
+                if (!(e < last_key)) continue;  // the first insert tightened the bound
+                uint32_t pos = 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) pos += (uint32_t)__popcll(__ballot((L[r] & LK_MASK) < e));
+                // entries from pos on move up by one: entry i takes entry i - 1, i.e. register r takes
+                // register r - 1 of the same lane, register 0 takes register R - 1 of the lane below
+                const uint32_t plo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)L[R - 1], 0x138, 0xF, 0xF, false);
+                const uint32_t phi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(L[R - 1] >> 32), 0x138, 0xF, 0xF, false);
+                u64 below = ((u64)phi << 32) | plo;
+#pragma unroll
+                for (int r = R - 1; r >= 0; r--) {
+                    const uint32_t idx = (uint32_t)(R * lane + r);
+                    const u64 from = r > 0 ? L[r > 0 ? r - 1 : 0] : below;
+                    L[r] = idx < pos ? L[r] : (idx == pos ? e : from);
+                }
+                n_cur = min(n_cur + 1, ef);
+                if (ef < 64u * R) {
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+                        if ((uint32_t)(R * lane + r) >= ef) L[r] = LK_INVALID;
+                }
+                refresh_last(ef);
+            }
+            return;
+        }
+        // rank of every survivor among list + survivors, shift of every list entry; scatter via LDS
+        uint32_t shift[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) shift[r] = 0;
+        uint32_t my_rank = 0;
+        u64 it = smask;
+        while (it) {
+            const uint32_t j = (uint32_t)__ffsll((long long)it) - 1;
+            it &= it - 1;
+            const u64 e = rdlane64(key, j);
+            uint32_t below = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const bool lt = (L[r] & LK_MASK) < e;
+                below += (uint32_t)__popcll(__ballot(lt));
+                shift[r] += lt ? 0u : 1u;
+            }
+            if (surv && e < key) my_rank++;
+            if ((uint32_t)lane == j) my_rank += below;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t idx = (uint32_t)(R * lane + r);
+            const uint32_t np = idx + shift[r];
+            if (idx < n_cur && np < ef) perm[np] = L[r];
+        }
+        if (surv && my_rank < ef) perm[my_rank] = key;
+        n_cur = min(n_cur + m, ef);
+        lds_fence();
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t idx = (uint32_t)(R * lane + r);
+            L[r] = idx < n_cur ? perm[idx] : LK_INVALID;
+        }
+        lds_fence();
+        refresh_last(ef);
+    }
+};
+
+// FullVec::distance of one row per lane against the query held in registers (full.rs:23-29): x - y and
+// the square two elements per instruction (each element the same single-rounded IEEE operations), the
+// sum one serial chain in element order
+template <int DS>
+__device__ __forceinline__ float row_dist(const float *rows, uint32_t id, bool want, const float (&qv)[DS]) {
+    constexpr int P = DS / 4;
+    float s = 0.0f;
+    if (want) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(rows + (size_t)id * DS);
+        uint4 w[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) w[p] = src[p];
+        __builtin_amdgcn_sched_barrier(0);  // every piece requested before the chain starts
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const uint32_t dw[4] = {w[p].x, w[p].y, w[p].z, w[p].w};
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const f32x2 x = {__builtin_bit_cast(float, dw[j]), __builtin_bit_cast(float, dw[j + 1])};
+                const f32x2 y = {qv[4 * p + j], qv[4 * p + j + 1]};
+                const f32x2 t = x - y;
+                const f32x2 t2 = t * t;
+                s += t2.x;
+                s += t2.y;
+            }
+        }
+    }
+    return __builtin_sqrtf(s);
+}
+
+template <int DS, int R>
+__global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
+    static_assert(DS % 4 == 0, "whole 16-byte pieces");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t q = a.qsel ? a.qsel[blockIdx.x] : blockIdx.x;
+    const uint32_t hslots = 1u << a.slots_log2;
+    u64 *perm = reinterpret_cast<u64 *>(smem + 4ull * hslots);
+    Visited vis;
+    vis.tab = reinterpret_cast<uint32_t *>(smem);
+
+    uint32_t n_dist = 0, n_exp = 0, sum_deg = 0, n_vis = 0;
+    int32_t status = HNSW_OK;
+
+    // ---- the query: every lane holds all DS values (Point::new of a FullVec is the vector itself) ----
+    const float *qp = a.Q + (size_t)q * DS;
+    float qv[DS];
+#pragma unroll
+    for (int e = 0; e < DS; e++) qv[e] = qp[e];
+    {
+        bool bad = false;
+        for (int e = lane; e < DS; e += 64) {
+            const float x = qp[e];
+            bad |= (x != x);
+        }
+        if (__ballot(bad)) status = HNSW_ERR_NAN_INPUT;  // partial_cmp().unwrap() panics in the reference
+    }
+#pragma unroll
+    for (int e = 0; e < DS; e++) asm volatile("" : "+v"(qv[e]));  // pinned to VGPRs for the whole kernel
+
+    // ---- entry point (template.rs:316-319) ----
+    u64 best = LK_INVALID;
+    uint32_t cur = a.ep;
+    if (status == HNSW_OK) {
+        if (cur >= a.n_points) {
+            status = HNSW_ERR_ARG;
+        } else {
+            const float d0 = row_dist<DS>(a.rows, cur, lane == 0, qv);
+            const uint32_t bits = rdlane(__builtin_bit_cast(uint32_t, d0), 0);
+            n_dist = 1;
+            if (__builtin_bit_cast(float, bits) != __builtin_bit_cast(float, bits))
+                status = HNSW_ERR_NAN_INPUT;
+            else
+                best = ((u64)bits << 32) | cur;
+        }
+    }
+
+    // ---- upper layers, ef = 1 (template.rs:322-324): a greedy walk.  With one slot in `selected`
+    // every fresh neighbour below the running best replaces it (searcher.rs:74-94), the next pop is
+    // the best found so far, and once an expansion improves nothing the next pop is a leftover above
+    // the best and the loop breaks (searcher.rs:41-44).  visited (cleared per layer, searcher.rs:101)
+    // only keeps the distance counter honest here. ----
+    const uint32_t up_slots = max(hslots >> 2, 64u);
+    uint32_t ub_cur = HX_EMPTY_SLOT;
+    bool have_ub = false;
+    for (int layer = (int)a.nb_layers - 1; layer >= 1 && status == HNSW_OK; layer--) {
+        vis.bshift = 32 - (__ffs((int)up_slots) - 1 - 2);
+        vis.bmask = (up_slots >> 2) - 1;
+        const uint32_t vis_limit = up_slots - (up_slots >> 2);
+        vis.clear(up_slots, lane);
+        vis.insert(cur, lane == 0);
+        n_vis = 1;
+        if (!have_ub) {
+            ub_cur = uni(a.upper_base[cur]);
+            have_ub = true;
+        }
+        while (status == HNSW_OK) {
+            if (ub_cur == HX_EMPTY_SLOT) {  // Graph::neighbors_vec -> NodeNotInGraph (searcher.rs:45-50)
+                status = HNSW_ERR_NODE_NOT_IN_GRAPH;
+                break;
+            }
+            n_exp++;
+            bool improved = false;
+            uint32_t new_cur = cur, new_ub = ub_cur;
+            const uint32_t *row = a.adj_up + ((size_t)ub_cur + (uint32_t)layer - 1) * a.S1;
+            uint32_t ovf_lo = 0, ovf_hi = 0;
+            bool first = true;
+            while (true) {
+                uint32_t nb = HX_EMPTY_SLOT;
+                if (first) {
+                    if ((uint32_t)lane < a.S1) nb = row[lane];
+                } else {
+                    if (ovf_lo + lane < ovf_hi) nb = a.ovf_nbrs[ovf_lo + lane];
+                    ovf_lo += 64;
+                }
+                const bool valid = (int32_t)nb >= 0;
+                if (first) {
+                    const u64 pm = __ballot((int32_t)nb < 0 && nb != HX_EMPTY_SLOT);
+                    if (pm) {
+                        const uint32_t o = rdlane(nb, (uint32_t)__ffsll((long long)pm) - 1) & ~HX_OVF_FLAG;
+                        ovf_lo = uni(a.ovf_off[o]);
+                        ovf_hi = uni(a.ovf_off[o + 1]);
+                    }
+                    first = false;
+                }
+                const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
+                sum_deg += cnt;
+                if (cnt != 0) {
+                    if (n_vis + cnt > vis_limit) {
+                        status = HNSW_ERR_OVERFLOW;
+                        break;
+                    }
+                    const bool fresh = vis.insert(nb, valid);
+                    const u64 fm = __ballot(fresh);
+                    const uint32_t nf = (uint32_t)__popcll(fm);
+                    n_vis += nf;
+                    n_dist += nf;
+                    if (fm) {
+                        uint32_t ubn = HX_EMPTY_SLOT;
+                        if (fresh) ubn = a.upper_base[nb];  // in flight together with the vector row
+                        const float dist = row_dist<DS>(a.rows, nb, fresh, qv);
+                        const bool nan = fresh && dist != dist;
+                        if (__ballot(nan)) {
+                            status = HNSW_ERR_NAN_INPUT;  // Dist::cmp would panic (dist.rs:32)
+                            break;
+                        }
+                        const uint32_t db = fresh ? __builtin_bit_cast(uint32_t, dist) : 0xFFFFFFFFu;
+                        const uint32_t mn = wave_min_u32(db);
+                        u64 tie = __ballot(fresh && db == mn);
+                        uint32_t j = (uint32_t)__ffsll((long long)tie) - 1;
+                        uint32_t bid = rdlane(nb, j);
+                        tie &= tie - 1;
+                        while (tie) {  // equal distances: the smaller id wins (dist.rs:30-38)
+                            const uint32_t j2 = (uint32_t)__ffsll((long long)tie) - 1;
+                            tie &= tie - 1;
+                            const uint32_t id2 = rdlane(nb, j2);
+                            if (id2 < bid) {
+                                bid = id2;
+                                j = j2;
+                            }
+                        }
+                        const u64 k = ((u64)mn << 32) | bid;
+                        if (k < best) {
+                            best = k;
+                            new_cur = bid;
+                            new_ub = rdlane(ubn, j);
+                            improved = true;
+                        }
+                    }
+                }
+                if (ovf_lo >= ovf_hi) break;
+            }
+            if (!improved || status != HNSW_OK) break;
+            cur = new_cur;
+            ub_cur = new_ub;
+        }
+    }
+
+    // ---- layer 0 with ef (template.rs:326) ----
+    const uint32_t ef = max(1u, a.ef);
+    Lst<R> lst;
+    lst.init();
+    if (status == HNSW_OK) {
+        vis.bshift = 32 - (a.slots_log2 - 2);
+        vis.bmask = (hslots >> 2) - 1;
+        const uint32_t vis_limit = hslots - (hslots >> 2);  // 75 % load at most
+        vis.clear(hslots, lane);
+        vis.insert(cur, lane == 0);
+        n_vis = 1;
+        if (lane == 0) lst.L[0] = best;
+        lst.n_cur = 1;
+        lst.refresh_last(ef);
+        const uint32_t S0 = a.S0;
+        const bool upper = lane >= 32;
+        const uint32_t slot = (uint32_t)lane & 31u;
+
+        int cpos = lst.first_unexp();
+        while (cpos >= 0) {
+            // ---- pick c (the smallest unexpanded entry) and the runner-up p ----
+            const uint32_t cid = lst.id_at((uint32_t)cpos);
+            lst.mark((uint32_t)cpos, lane);
+            n_exp++;
+            const int ppos = lst.first_unexp();
+            const uint32_t pid = ppos >= 0 ? lst.id_at((uint32_t)ppos) : cid;
+            uint32_t nb = HX_EMPTY_SLOT;
+            if (slot < S0) nb = a.adj0[(size_t)(upper ? pid : cid) * S0 + slot];
+            const u64 pm = __ballot((int32_t)nb < 0 && nb != HX_EMPTY_SLOT);
+            // a runner-up row with an overflow pointer is not speculated on
+            const bool spec_ok = ppos >= 0 && (pm >> 32) == 0;
+            const bool valid = (int32_t)nb >= 0 && (!upper || spec_ok);
+            uint32_t c_ovf = HX_EMPTY_SLOT;
+            if (pm & 0xFFFFFFFFull)
+                c_ovf = rdlane(nb, (uint32_t)__ffsll((long long)(pm & 0xFFFFFFFFull)) - 1) & ~HX_OVF_FLAG;
+            const u64 vmask = __ballot(valid);
+            const uint32_t cnt_c = (uint32_t)__popcll(vmask & 0xFFFFFFFFull);
+            const uint32_t cnt_p = (uint32_t)__popcll(vmask >> 32);
+            sum_deg += cnt_c;
+            if (n_vis + cnt_c > vis_limit) {
+                status = HNSW_ERR_OVERFLOW;
+                break;
+            }
+            // ---- visited: c's lanes insert; p's lanes only look (p's real insert happens at its commit,
+            // after everything c inserted; a stale "absent" merely evaluates a distance for nothing) ----
+            uint32_t b = vis.home(nb);
+            bool found, again;
+            bool fresh = vis.round(nb, valid && !upper, b, found, again);
+            while (__ballot(again)) {
+                bool f2, a2 = false, w = false;
+                if (again) w = vis.round(nb, true, b, f2, a2);
+                fresh |= w;
+                again = again & a2;
+            }
+            const uint32_t nf_c = (uint32_t)__popcll(__ballot(fresh));
+            n_vis += nf_c;
+            n_dist += nf_c;
+            const bool want = upper ? (valid && !found) : fresh;
+            u64 key = LK_INVALID;
+            bool nan = false;
+            if (__ballot(want)) {
+                const float dist = row_dist<DS>(a.rows, nb, want, qv);
+                nan = want && dist != dist;
+                if (want && !nan) key = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | nb;
+            }
+            if (__ballot(nan && !upper)) {
+                status = HNSW_ERR_NAN_INPUT;
+                break;
+            }
+            lst.merge(upper ? LK_INVALID : key, ef, perm, lane);
+            if (c_ovf != HX_EMPTY_SLOT) {  // degree > S0: the rest of c's row (rare)
+                const uint32_t lo = uni(a.ovf_off[c_ovf]), hi = uni(a.ovf_off[c_ovf + 1]);
+                for (uint32_t base = lo; base < hi && status == HNSW_OK; base += 32) {
+                    const uint32_t i = base + lane;
+                    const bool ov = lane < 32 && i < hi;
+                    const uint32_t onb = ov ? a.ovf_nbrs[i] : HX_EMPTY_SLOT;
+                    const uint32_t ocnt = (uint32_t)__popcll(__ballot(ov));
+                    sum_deg += ocnt;
+                    if (n_vis + ocnt > vis_limit) {
+                        status = HNSW_ERR_OVERFLOW;
+                        break;
+                    }
+                    const bool ofresh = vis.insert(onb, ov);
+                    const uint32_t onf = (uint32_t)__popcll(__ballot(ofresh));
+                    n_vis += onf;
+                    n_dist += onf;
+                    if (onf == 0) continue;
+                    const float odist = row_dist<DS>(a.rows, onb, ofresh, qv);
+                    if (__ballot(ofresh && odist != odist)) {
+                        status = HNSW_ERR_NAN_INPUT;
+                        break;
+                    }
+                    lst.merge(ofresh ? (((u64)__builtin_bit_cast(uint32_t, odist) << 32) | onb) : LK_INVALID, ef,
+                              perm, lane);
+                }
+                if (status != HNSW_OK) break;
+            }
+            // ---- is p the next candidate?  then commit it from the registers ----
+            cpos = lst.first_unexp();
+            if (cpos < 0) break;
+            if (!spec_ok) continue;
+            if (lst.id_at((uint32_t)cpos) != pid) continue;
+            lst.mark((uint32_t)cpos, lane);
+            n_exp++;
+            sum_deg += cnt_p;
+            if (n_vis + cnt_p > vis_limit) {
+                status = HNSW_ERR_OVERFLOW;
+                break;
+            }
+            // every valid neighbour of p goes through the filter now: one that c's commit inserted
+            // meanwhile is dropped, one that was skipped above was in the set already
+            const bool pfresh = vis.insert(nb, valid && upper);
+            const uint32_t nf_p = (uint32_t)__popcll(__ballot(pfresh));
+            n_vis += nf_p;
+            n_dist += nf_p;
+            if (__ballot(pfresh && nan)) {
+                status = HNSW_ERR_NAN_INPUT;
+                break;
+            }
+            lst.merge(pfresh ? key : LK_INVALID, ef, perm, lane);
+            cpos = lst.first_unexp();
+        }
+    }
+
+    // ---- get_top_selected(n) (results.rs:59-61): the first n entries of the ascending list ----
+    const uint32_t count = status == HNSW_OK ? min(a.n, lst.n_cur) : 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t idx = (uint32_t)(R * lane + r);
+        if (idx < a.n) {
+            const bool have = idx < count;
+            a.out_ids[(size_t)q * a.n + idx] = have ? (uint32_t)lst.L[r] : HX_EMPTY_SLOT;
+            if (a.out_dists)
+                a.out_dists[(size_t)q * a.n + idx] =
+                    have ? __builtin_bit_cast(float, (uint32_t)((lst.L[r] & LK_MASK) >> 32)) : __builtin_inff();
+        }
+    }
+    for (uint32_t idx = 64u * R + lane; idx < a.n; idx += 64) {  // n beyond the list capacity: padding
+        a.out_ids[(size_t)q * a.n + idx] = HX_EMPTY_SLOT;
+        if (a.out_dists) a.out_dists[(size_t)q * a.n + idx] = __builtin_inff();
+    }
+    if (lane == 0) {
+        if (a.out_counts) a.out_counts[q] = count;
+        hnsw_query_stats st;
+        st.n_dist = n_dist;
+        st.n_exp = n_exp;
+        st.sum_deg = sum_deg;
+        st.status = status;
+        a.out_stats[q] = st;
+    }
+}
+
+template <int DS, int R>
+int launch_lean_one(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
+    const size_t lds = (4ull << a.slots_log2) + 64ull * R * 8;
+    auto kern = hx_lean_f32_kernel<DS, R>;
+    if (lds > 160 * 1024) {
+        set_error("search needs %zu bytes of LDS (> 160 KiB)", lds);
+        return HNSW_ERR_ARG;
+    }
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+            return HNSW_ERR_HIP;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64), lds, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("search kernel launch: %s", hipGetErrorString(e));
+        return HNSW_ERR_HIP;
+    }
+    return HNSW_OK;
+}
+
+}  // namespace
+
+// Whether the lean kernel serves this search: the whole ann_by_vector descent over f32 rows of a
+// dimension it is built for, lists of at most two registers.  HNSW_MI355X_LEAN=0 turns it off (A/B).
+bool lean_applicable(const DevView &v, const SearchArgs &a, uint32_t ef_max) {
+    static const bool enabled = !(getenv("HNSW_MI355X_LEAN") && atoi(getenv("HNSW_MI355X_LEAN")) == 0);
+    if (!enabled) return false;
+    if (v.kind != HNSW_VEC_F32 || v.dim != 100 || v.row_stride != 400) return false;
+    if (a.entries != nullptr || a.layer_lo != 0 || a.layer_hi != (int32_t)v.nb_layers - 1) return false;
+    if (a.layer_hi > 0 && a.ef_upper != 1) return false;
+    if (v.S0 > 32 || v.S1 > 64 || ef_max > 128 || (a.flags & 1u)) return false;
+    return true;
+}
+
+int launch_lean(const DevView &v, const SearchArgs &s, uint32_t nblocks, uint32_t slots_log2, hipStream_t stream) {
+    LeanArgs a{};
+    a.rows = reinterpret_cast<const float *>(v.rows);
+    a.adj0 = v.adj0;
+    a.adj_up = v.adj_up;
+    a.upper_base = v.upper_base;
+    a.ovf_off = v.ovf_off;
+    a.ovf_nbrs = v.ovf_nbrs;
+    a.Q = s.Q;
+    a.qsel = s.qsel;
+    a.out_ids = s.out_ids;
+    a.out_dists = s.out_dists;
+    a.out_counts = s.out_counts;
+    a.out_stats = s.out_stats;
+    a.n_points = v.n_points;
+    a.ep = v.ep;
+    a.nb_layers = v.nb_layers;
+    a.S0 = v.S0;
+    a.S1 = v.S1;
+    a.ef = s.ef_bottom;
+    a.n = s.n;
+    a.slots_log2 = slots_log2;
+    if (a.ef <= 64) return launch_lean_one<100, 1>(a, nblocks, stream);
+    return launch_lean_one<100, 2>(a, nblocks, stream);
+}
+
+}  // namespace hx
