@@ -55,7 +55,27 @@ struct LeanArgs {
     uint32_t *out_counts;
     hnsw_query_stats *out_stats;
     uint32_t n_points, ep, nb_layers, S0, S1, ef, n, slots_log2;
+    unsigned long long *dbg;  // diagnostic builds only (HX_STAMPS)
 };
+
+// Diagnostic build only (make stamps): per-phase cycle sums, written to a side buffer nothing else reads.
+#ifdef HX_STAMPS
+// a stamp drains the wave's memory counters and is a scheduling barrier, so that what lies between two
+// stamps is exactly the code written between them
+__device__ __forceinline__ unsigned long long stamp_now() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long t = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define STAMP(var) const unsigned long long var = stamp_now()
+#define STAMP_ADD(slot, a, b) dbg_acc[slot] += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(slot, a, b)
+#endif
 
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
@@ -79,7 +99,11 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// visited set (IntSet::insert, results.rs:101-103): open addressing over buckets of four slots
+// visited set (IntSet::insert, results.rs:101-103): open addressing over buckets of four slots.
+// Slots of a bucket fill left to right and never empty again; ids are < 2^31 and an empty slot is
+// 0xFFFFFFFF, so the number of slots with a clear sign bit is the index of the first empty one.
+// Everything a lane decides stays in vector registers (a wave alone on its SIMD pays ~20 cycles for
+// every vector -> scalar hand-off and ~25 for every branch: scripts/micro/issue_cost.hip).
 // ---------------------------------------------------------------------------------------------
 struct Visited {
     uint32_t *tab;
@@ -87,36 +111,44 @@ struct Visited {
 
     __device__ __forceinline__ uint32_t home(uint32_t id) const { return (id * 0x9E3779B1u) >> bshift; }
 
-    // One straight-line round for the whole wave.  Every lane reads its home bucket; `found` tells
-    // whether the id is in it.  Lanes with ins == true try to claim the first empty slot.  Returns
-    // true for the lanes that inserted their id; lanes that could not finish (slot lost to another
-    // lane of this round, or bucket full) come back in `again` with `b` set to the bucket to look at.
-    __device__ __forceinline__ bool round(uint32_t id, bool ins, uint32_t &b, bool &found, bool &again) const {
+    // state of bucket b with respect to id: 0..3 = id absent, this is the first empty slot;
+    // 4 = id present; 5 = id absent and the bucket is full
+    __device__ __forceinline__ uint32_t look(uint32_t id, uint32_t b) const {
         const uint4 bk = *reinterpret_cast<const uint4 *>(tab + 4 * b);
-        found = (bk.x == id) | (bk.y == id) | (bk.z == id) | (bk.w == id);
-        const int j = bk.x == HX_EMPTY_SLOT ? 0 : bk.y == HX_EMPTY_SLOT ? 1 : bk.z == HX_EMPTY_SLOT ? 2
-                      : bk.w == HX_EMPTY_SLOT ? 3 : 4;
-        const bool claim = ins & !found & (j < 4);
-        uint32_t old = 0;
-        if (claim) old = atomicCAS(tab + 4 * b + j, HX_EMPTY_SLOT, id);
-        const bool won = claim & (old == HX_EMPTY_SLOT);
-        again = ins & !found & !won;
-        if (ins & !found & (j == 4)) b = (b + 1) & bmask;  // full: the next bucket; a lost slot: same bucket again
-        return won;
+        const uint32_t m = min(min(bk.x ^ id, bk.y ^ id), min(bk.z ^ id, bk.w ^ id));
+        const uint32_t nf = 4u + (uint32_t)(((int32_t)bk.x >> 31) + ((int32_t)bk.y >> 31) + ((int32_t)bk.z >> 31) +
+                                            ((int32_t)bk.w >> 31));
+        return m == 0 ? 4u : (nf == 4u ? 5u : nf);
     }
-    // exact insert of the lanes with ins == true (ids of one call are distinct); true = was absent
-    __device__ __forceinline__ bool insert(uint32_t id, bool ins) const {
-        uint32_t b = home(id);
-        bool found, again;
-        bool fresh = round(id, ins, b, found, again);
-        while (__ballot(again)) {
-            bool f2, a2 = false;
-            bool w = false;
-            if (again) w = round(id, true, b, f2, a2);
-            fresh |= w;
-            again = again & a2;
+    // claims slot t of bucket b for id where t < 4; returns what the slot held (0 for t >= 4)
+    __device__ __forceinline__ uint32_t claim(uint32_t id, uint32_t b, uint32_t t) const {
+        uint32_t old = 0;
+        if (t < 4u) old = atomicCAS(tab + 4 * b + t, HX_EMPTY_SLOT, id);
+        return old;
+    }
+    // the lanes that could not finish in their first round: a slot lost to another lane (look again at
+    // the same bucket) or a full bucket (the next one).  Rare; the only loop of the filter.
+    __device__ __forceinline__ bool finish(uint32_t id, uint32_t b, uint32_t t, bool pend, bool fresh) const {
+        while (__ballot(pend)) {
+            if (pend) {
+                if (t == 5u) b = (b + 1) & bmask;
+                t = look(id, b);
+                const uint32_t old = claim(id, b, t);
+                const bool won = old == HX_EMPTY_SLOT;
+                fresh |= won;
+                pend = (t != 4u) & !won;
+            }
         }
         return fresh;
+    }
+    // exact insert of the lanes with ins == true (the ids of one call are distinct); true = was absent
+    __device__ __forceinline__ bool insert(uint32_t id, bool ins) const {
+        const uint32_t b = home(id);
+        uint32_t t = look(id, b);
+        t = ins ? t : 4u;
+        const uint32_t old = claim(id, b, t);
+        const bool fresh = old == HX_EMPTY_SLOT;
+        return finish(id, b, t, (t != 4u) & !fresh, fresh);
     }
     __device__ __forceinline__ void clear(uint32_t nslots, int lane) const {
         for (uint32_t s = lane; s < (nslots >> 2); s += 64)
@@ -151,26 +183,23 @@ struct Lst {
         }
         return (int)pos;
     }
-    // the two smallest unexpanded entries
-    __device__ __forceinline__ void first_two(int &a, int &b) const {
-        u64 U[R];
-        uint32_t pa = 0xFFFFFFFFu;
+    // ballots of the entries not expanded yet, and "take the smallest of them" on those masks: several
+    // picks cost one vector -> scalar hand-off
+    __device__ __forceinline__ void unexp_masks(u64 (&U)[R]) const {
+#pragma unroll
+        for (int r = 0; r < R; r++) U[r] = __ballot((int32_t)(uint32_t)(L[r] >> 32) >= 0);
+    }
+    static __device__ __forceinline__ int take_first(u64 (&U)[R]) {
+        uint32_t pos = 0xFFFFFFFFu;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            U[r] = __ballot((int32_t)(uint32_t)(L[r] >> 32) >= 0);
             const uint32_t i = U[r] ? (uint32_t)(R * (__ffsll((long long)U[r]) - 1) + r) : 0xFFFFFFFFu;
-            pa = min(pa, i);
+            pos = min(pos, i);
         }
-        uint32_t pb = 0xFFFFFFFFu;
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            u64 V = U[r];
-            if (pa != 0xFFFFFFFFu && (pa % R) == (uint32_t)r) V &= ~(1ull << (pa / R));
-            const uint32_t i = V ? (uint32_t)(R * (__ffsll((long long)V) - 1) + r) : 0xFFFFFFFFu;
-            pb = min(pb, i);
-        }
-        a = (int)pa;
-        b = (int)pb;
+        for (int r = 0; r < R; r++)
+            if (pos != 0xFFFFFFFFu && (pos % R) == (uint32_t)r) U[r] &= U[r] - 1;  // its lowest set bit
+        return (int)pos;
     }
     __device__ __forceinline__ uint32_t id_at(uint32_t pos) const {
         uint32_t v = 0;
@@ -280,7 +309,8 @@ struct Lst {
 // the square two elements per instruction (each element the same single-rounded IEEE operations), the
 // sum one serial chain in element order
 template <int DS>
-__device__ __forceinline__ float row_dist(const float *rows, uint32_t id, bool want, const float (&qv)[DS]) {
+__device__ __forceinline__ float row_dist(const float *rows, uint32_t id, bool want, const float (&qv)[DS],
+                                          unsigned long long *t_landed = nullptr) {
     constexpr int P = DS / 4;
     float s = 0.0f;
     if (want) {
@@ -289,6 +319,9 @@ __device__ __forceinline__ float row_dist(const float *rows, uint32_t id, bool w
 #pragma unroll
         for (int p = 0; p < P; p++) w[p] = src[p];
         __builtin_amdgcn_sched_barrier(0);  // every piece requested before the chain starts
+#ifdef HX_STAMPS
+        if (t_landed) *t_landed = stamp_now();
+#endif
 #pragma unroll
         for (int p = 0; p < P; p++) {
             const uint32_t dw[4] = {w[p].x, w[p].y, w[p].z, w[p].w};
@@ -319,6 +352,10 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
 
     uint32_t n_dist = 0, n_exp = 0, sum_deg = 0, n_vis = 0;
     int32_t status = HNSW_OK;
+#ifdef HX_STAMPS
+    unsigned long long dbg_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
 
     // ---- the query: every lane holds all DS values (Point::new of a FullVec is the vector itself) ----
     const float *qp = a.Q + (size_t)q * DS;
@@ -455,6 +492,9 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
     }
 
     // ---- layer 0 with ef (template.rs:326) ----
+#ifdef HX_STAMPS
+    dbg_acc[7] = __builtin_readcyclecounter() - t_begin;  // query staging + entry point + upper layers
+#endif
     const uint32_t ef = max(1u, a.ef);
     Lst<R> lst;
     lst.init();
@@ -471,60 +511,104 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
         const uint32_t S0 = a.S0;
         const bool upper = lane >= 32;
         const uint32_t slot = (uint32_t)lane & 31u;
+        // the adjacency rows fetched ahead for the pass after this one (see below)
+        uint32_t pre_nb = HX_EMPTY_SLOT, pre_c = HX_EMPTY_SLOT, pre_p = HX_EMPTY_SLOT;
 
-        int cpos = lst.first_unexp();
-        while (cpos >= 0) {
-            // ---- pick c (the smallest unexpanded entry) and the runner-up p ----
+        while (true) {
+            // ---- pick c (the smallest unexpanded entry) and the runner-up p: one set of ballots ----
+            STAMP(f0);
+            u64 U[R];
+            lst.unexp_masks(U);
+            const int cpos = Lst<R>::take_first(U);
+            if (cpos < 0) break;  // candidates exhausted / only worse ones left (searcher.rs:35,41-44)
+            const int ppos = Lst<R>::take_first(U);
             const uint32_t cid = lst.id_at((uint32_t)cpos);
+            const uint32_t pid = ppos >= 0 ? lst.id_at((uint32_t)ppos) : HX_EMPTY_SLOT;
             lst.mark((uint32_t)cpos, lane);
             n_exp++;
-            const int ppos = lst.first_unexp();
-            const uint32_t pid = ppos >= 0 ? lst.id_at((uint32_t)ppos) : cid;
-            uint32_t nb = HX_EMPTY_SLOT;
-            if (slot < S0) nb = a.adj0[(size_t)(upper ? pid : cid) * S0 + slot];
-            const u64 pm = __ballot((int32_t)nb < 0 && nb != HX_EMPTY_SLOT);
-            // a runner-up row with an overflow pointer is not speculated on
+            uint32_t nb;
+            if (pre_c == cid && pre_p == pid) {
+                nb = pre_nb;  // both rows were requested during the previous pass
+            } else {
+                nb = HX_EMPTY_SLOT;
+                if (slot < S0 && (!upper || ppos >= 0)) nb = a.adj0[(size_t)(upper ? pid : cid) * S0 + slot];
+            }
+            pre_c = HX_EMPTY_SLOT;
+#ifdef HX_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg_acc[6]++;
+#endif
+            STAMP(f1);
+            STAMP_ADD(0, f0, f1);
+            // ---- classify the slots.  A row with an overflow pointer (degree > S0) is rare: c's is
+            // finished after the merge, a runner-up with one is not speculated on ----
+            const u64 pm = __ballot((int32_t)nb < -1);  // 0x80000000 | overflow row
             const bool spec_ok = ppos >= 0 && (pm >> 32) == 0;
             const bool valid = (int32_t)nb >= 0 && (!upper || spec_ok);
-            uint32_t c_ovf = HX_EMPTY_SLOT;
-            if (pm & 0xFFFFFFFFull)
-                c_ovf = rdlane(nb, (uint32_t)__ffsll((long long)(pm & 0xFFFFFFFFull)) - 1) & ~HX_OVF_FLAG;
-            const u64 vmask = __ballot(valid);
+            // ---- visited: every lane looks at its home bucket; c's lanes claim a slot, p's lanes only
+            // look (p's real insert happens at its commit, after everything c inserted; a stale "absent"
+            // merely evaluates a distance for nothing) ----
+            const uint32_t vb = vis.home(nb);
+            const uint32_t vt0 = vis.look(nb, vb);
+            const uint32_t vt = valid ? vt0 : 4u;       // 0..3 claimable slot, 4 nothing to do, 5 bucket full
+            const uint32_t ct = upper ? 4u : vt;
+            const uint32_t old = vis.claim(nb, vb, ct);
+            bool fresh = old == HX_EMPTY_SLOT;          // c's lanes that inserted their id
+            const bool pend = (ct != 4u) & !fresh;
+            if (__ballot(pend)) {
+                fresh = vis.finish(nb, vb, ct, pend, fresh);
+#ifdef HX_STAMPS
+                dbg_acc[11]++;
+#endif
+            }
+            const bool want = upper ? (vt != 4u) : fresh;
+            const u64 vmask = __ballot(valid), fmask = __ballot(fresh);
             const uint32_t cnt_c = (uint32_t)__popcll(vmask & 0xFFFFFFFFull);
             const uint32_t cnt_p = (uint32_t)__popcll(vmask >> 32);
+            const uint32_t nf_c = (uint32_t)__popcll(fmask);
             sum_deg += cnt_c;
-            if (n_vis + cnt_c > vis_limit) {
+            n_vis += nf_c;
+            n_dist += nf_c;
+            // the table holds at most vis_limit + 64 ids (checked after the inserts: one hand-off less)
+            if (n_vis > vis_limit) {
                 status = HNSW_ERR_OVERFLOW;
                 break;
             }
-            // ---- visited: c's lanes insert; p's lanes only look (p's real insert happens at its commit,
-            // after everything c inserted; a stale "absent" merely evaluates a distance for nothing) ----
-            uint32_t b = vis.home(nb);
-            bool found, again;
-            bool fresh = vis.round(nb, valid && !upper, b, found, again);
-            while (__ballot(again)) {
-                bool f2, a2 = false, w = false;
-                if (again) w = vis.round(nb, true, b, f2, a2);
-                fresh |= w;
-                again = again & a2;
-            }
-            const uint32_t nf_c = (uint32_t)__popcll(__ballot(fresh));
-            n_vis += nf_c;
-            n_dist += nf_c;
-            const bool want = upper ? (valid && !found) : fresh;
             u64 key = LK_INVALID;
             bool nan = false;
+            STAMP(f2);
+            STAMP_ADD(1, f1, f2);
+#ifdef HX_STAMPS
+            unsigned long long t_landed = f2;
+#endif
             if (__ballot(want)) {
+#ifdef HX_STAMPS
+                const float dist = row_dist<DS>(a.rows, nb, want, qv, &t_landed);
+#else
                 const float dist = row_dist<DS>(a.rows, nb, want, qv);
+#endif
                 nan = want && dist != dist;
                 if (want && !nan) key = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | nb;
             }
-            if (__ballot(nan && !upper)) {
-                status = HNSW_ERR_NAN_INPUT;
+            STAMP(f3);
+            STAMP_ADD(2, f2, t_landed);
+            STAMP_ADD(3, t_landed, f3);
+#ifdef HX_STAMPS
+            {
+                const uint32_t mm = (uint32_t)__popcll(__ballot(!upper && key < lst.last_key));
+                dbg_acc[mm == 0 ? 12 : mm <= 2 ? 13 : 14]++;
+            }
+#endif
+            const u64 nanm = __ballot(nan);
+            if (nanm & 0xFFFFFFFFull) {
+                status = HNSW_ERR_NAN_INPUT;  // Dist::cmp would panic (dist.rs:32)
                 break;
             }
             lst.merge(upper ? LK_INVALID : key, ef, perm, lane);
-            if (c_ovf != HX_EMPTY_SLOT) {  // degree > S0: the rest of c's row (rare)
+            STAMP(f3b);
+            STAMP_ADD(8, f3, f3b);
+            if (pm & 0xFFFFFFFFull) {  // degree > S0: the rest of c's row (rare)
+                const uint32_t c_ovf = rdlane(nb, (uint32_t)__ffsll((long long)(pm & 0xFFFFFFFFull)) - 1) & ~HX_OVF_FLAG;
                 const uint32_t lo = uni(a.ovf_off[c_ovf]), hi = uni(a.ovf_off[c_ovf + 1]);
                 for (uint32_t base = lo; base < hi && status == HNSW_OK; base += 32) {
                     const uint32_t i = base + lane;
@@ -552,29 +636,62 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
                 if (status != HNSW_OK) break;
             }
             // ---- is p the next candidate?  then commit it from the registers ----
-            cpos = lst.first_unexp();
-            if (cpos < 0) break;
             if (!spec_ok) continue;
-            if (lst.id_at((uint32_t)cpos) != pid) continue;
-            lst.mark((uint32_t)cpos, lane);
+            u64 V[R];
+            lst.unexp_masks(V);
+            const int npos = Lst<R>::take_first(V);
+            if (npos < 0) break;
+            if (lst.id_at((uint32_t)npos) != pid) continue;
+            // The pass after this one will most likely expand the two entries that follow p (measured:
+            // three times out of four when p is committed).  Their adjacency rows are requested now and
+            // land while p is being committed; if the next pick is a different pair they are dropped.
+            {
+                const int apos = Lst<R>::take_first(V);
+                if (apos >= 0) {
+                    const int bpos = Lst<R>::take_first(V);
+                    pre_c = lst.id_at((uint32_t)apos);
+                    pre_p = bpos >= 0 ? lst.id_at((uint32_t)bpos) : HX_EMPTY_SLOT;
+                    pre_nb = HX_EMPTY_SLOT;
+                    if (slot < S0 && (!upper || bpos >= 0)) pre_nb = a.adj0[(size_t)(upper ? pre_p : pre_c) * S0 + slot];
+                }
+            }
+            STAMP(f4);
+            STAMP_ADD(9, f3b, f4);
+            lst.mark((uint32_t)npos, lane);
             n_exp++;
+            // Every valid neighbour of p goes through the filter now.  The bucket state seen while
+            // speculating is still good for a direct claim: slots fill left to right, so if slot vt is
+            // still empty nothing entered the bucket since and the id is absent; if it now holds this very
+            // id, c's commit inserted it; anything else sends the lane through the full insert.
+            const uint32_t pt = upper ? vt : 4u;
+            const uint32_t pold = vis.claim(nb, vb, pt);
+            bool pfresh = pold == HX_EMPTY_SLOT;
+            const bool ppend = (pt == 5u) | ((pt < 4u) & !pfresh & (pold != nb));
+            if (__ballot(ppend)) pfresh = vis.finish(nb, vb, pt == 5u ? 5u : 0u, ppend, pfresh);
+            const uint32_t nf_p = (uint32_t)__popcll(__ballot(pfresh));
             sum_deg += cnt_p;
-            if (n_vis + cnt_p > vis_limit) {
+            n_vis += nf_p;
+            n_dist += nf_p;
+            if (n_vis > vis_limit) {
                 status = HNSW_ERR_OVERFLOW;
                 break;
             }
-            // every valid neighbour of p goes through the filter now: one that c's commit inserted
-            // meanwhile is dropped, one that was skipped above was in the set already
-            const bool pfresh = vis.insert(nb, valid && upper);
-            const uint32_t nf_p = (uint32_t)__popcll(__ballot(pfresh));
-            n_vis += nf_p;
-            n_dist += nf_p;
             if (__ballot(pfresh && nan)) {
                 status = HNSW_ERR_NAN_INPUT;
                 break;
             }
+            STAMP(f4b);
+            STAMP_ADD(5, f4, f4b);
+#ifdef HX_STAMPS
+            {
+                const uint32_t mm = (uint32_t)__popcll(__ballot(pfresh && key < lst.last_key));
+                dbg_acc[mm == 0 ? 12 : mm <= 2 ? 13 : 14]++;
+                dbg_acc[15]++;
+            }
+#endif
             lst.merge(pfresh ? key : LK_INVALID, ef, perm, lane);
-            cpos = lst.first_unexp();
+            STAMP(f5);
+            STAMP_ADD(10, f4b, f5);
         }
     }
 
@@ -595,6 +712,12 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
         a.out_ids[(size_t)q * a.n + idx] = HX_EMPTY_SLOT;
         if (a.out_dists) a.out_dists[(size_t)q * a.n + idx] = __builtin_inff();
     }
+#ifdef HX_STAMPS
+    if (lane == 0 && a.dbg) {
+        dbg_acc[4] = __builtin_readcyclecounter() - t_begin;
+        for (int i = 0; i < 16; i++) a.dbg[(size_t)q * 16 + i] = dbg_acc[i];
+    }
+#endif
     if (lane == 0) {
         if (a.out_counts) a.out_counts[q] = count;
         hnsw_query_stats st;
@@ -667,6 +790,7 @@ int launch_lean(const DevView &v, const SearchArgs &s, uint32_t nblocks, uint32_
     a.ef = s.ef_bottom;
     a.n = s.n;
     a.slots_log2 = slots_log2;
+    a.dbg = s.dbg;
     if (a.ef <= 64) return launch_lean_one<100, 1>(a, nblocks, stream);
     return launch_lean_one<100, 2>(a, nblocks, stream);
 }
