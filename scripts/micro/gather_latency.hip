@@ -209,7 +209,7 @@ static void run(const Args &a0, uint32_t nwaves, const char *name, double bytes_
 }
 
 int main(int argc, char **argv) {
-    const uint32_t N = 1000000, ITERS = 60;
+    const uint32_t N = argc > 2 ? (uint32_t)atoi(argv[2]) : 1000000, ITERS = 60;
     const bool with_blocks = argc < 2 || atoi(argv[1]) != 0;
     uint8_t *rows;
     uint32_t *adj;
@@ -250,7 +250,8 @@ int main(int argc, char **argv) {
     a.iters = ITERS;
     CK(hipMalloc(&a.cyc, 8192 * 4 * 8));
     CK(hipMalloc(&a.sink, 8192 * 4));
-    for (uint32_t nw : {1024u, 2048u, 4096u}) {
+    printf("table of %u rows\n", N);
+    for (uint32_t nw : {256u, 1024u, 2048u}) {
         run<0>(a, nw, "0 lane/row, 64 rows (2 cand)", 64 * 400 + 256);
         run<1>(a, nw, "1 lane/row, 32 rows", 32 * 400 + 128);
         run<2>(a, nw, "2 lane-pair/row, 32 rows", 32 * 400 + 128);
