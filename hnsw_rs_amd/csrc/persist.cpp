@@ -282,10 +282,27 @@ int load_index(const std::string &dir, std::unique_ptr<HostIndex> *out) {
             for (size_t k = 0; k < m; k++) {
                 const NodeID n = get_u32(&lb[off + 4 * k]);
                 if (n == UINT32_MAX) break;  // graph.rs:192: stop at the first sentinel
+                // the search kernels index the row arrays with what is stored here
+                if (!idx->in_layer(level, n) || n == id) {
+                    set_error("layer %u: node %u lists neighbour %u, which is not a node of that layer", level, id, n);
+                    return HNSW_ERR_IO;
+                }
                 if (std::find(r.begin(), r.end(), n) == r.end()) r.push_back(n);
             }
             off += 4 * m;
         }
+    }
+    // the entry point must be a stored point of the top layer (params.rs:13, template.rs:283-290), and the
+    // caps must be the ones the layers were built with (params.rs:20-42): both size device structures
+    if (len > 0 && (p.ep >= len || idx->levels[p.ep] + 1u != idx->layer_nodes.size())) {
+        set_error("params: entry point %u is not a node of the top layer", p.ep);
+        return HNSW_ERR_IO;
+    }
+    if (p.mmax < p.m || p.mmax0 < p.m || p.mmax > 65535 || p.mmax0 > 65535 || p.ef_cons == 0) {
+        set_error("params: mmax %llu / mmax0 %llu / ef_cons %llu are inconsistent with m %llu",
+                  (unsigned long long)p.mmax, (unsigned long long)p.mmax0, (unsigned long long)p.ef_cons,
+                  (unsigned long long)p.m);
+        return HNSW_ERR_IO;
     }
     idx->version = 1;
     *out = std::move(idx);

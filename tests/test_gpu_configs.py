@@ -1,0 +1,135 @@
+"""Parity at the shapes BASELINE.json's configs name and on every kernel instantiation `launch_search` can
+pick for them: the timed f32 d = 100 kernel at efSearch 64 .. 256, d = 128 and
+d = 768 at efSearch 64 / 128, all on indexes of >= 20 000 points built on the device, plus the device and the
+two-rank sharded build at d = 256.  Bar as everywhere: ids, distance bits and traversal counters identical
+to the CPU oracle (hnsw/src/template/searcher.rs:23-103, hnsw/src/template.rs:306-335)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import hnsw_rs_amd as H
+from oracle import oracle_py as O
+from tests.util import assert_search_equal, oracle_from_product
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def device_built(n, d, m, kind, recipe=0, unit=False):
+    vs = H.synth_rows(recipe, 0x5EED0001, 0, n, d)
+    qs = H.synth_rows(recipe, 0x5EED0002, 0, 128, d)
+    if unit:  # configs[2]: cosine order = L2 order on unit-normalised rows
+        vs /= np.linalg.norm(vs, axis=1, keepdims=True).astype(np.float32)
+        qs /= np.linalg.norm(qs, axis=1, keepdims=True).astype(np.float32)
+    lv = O.draw_levels(n, m, 0x5EED0003)
+    idx = H.HNSW.new(m, 32, d, kind)
+    idx.insert_bulk_device(vs, 8, False, levels=lv)
+    return idx, oracle_from_product(idx, vs, lv), qs
+
+
+@pytest.fixture(scope="module")
+def f32_100d():
+    return device_built(24000, 100, 16, H.VEC_F32)
+
+
+@pytest.mark.parametrize("ef", [64, 68, 96, 128, 129, 256])
+def test_the_timed_f32_kernel(f32_100d, ef):
+    """configs[1]: 100d f32, M = 16 -- the lean kernel with one (ef <= 64) and two (<= 128) list registers,
+    the generic kernel beyond"""
+    idx, orc, qs = f32_100d
+    assert_search_equal(idx.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=8), "f32 100d ef=%d" % ef)
+
+
+def test_the_generic_f32_kernel_still_agrees(f32_100d):
+    """HNSW_MI355X_LEAN=0 routes d = 100 f32 through hx_search_kernel's two-rows-per-pass loop (the round-1
+    kernel, still what serves every other dimension); the choice is read once per process"""
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import hnsw_rs_amd as H\n"
+        "from oracle import oracle_py as O\n"
+        "from tests.util import oracle_from_product, assert_search_equal\n"
+        "n, d, m = 20000, 100, 16\n"
+        "vs = H.synth_rows(0, 0x5EED0001, 0, n, d); qs = H.synth_rows(0, 0x5EED0002, 0, 128, d)\n"
+        "lv = O.draw_levels(n, m, 7)\n"
+        "idx = H.HNSW.new(m, 32, d, H.VEC_F32); idx.insert_bulk_device(vs, 8, False, levels=lv)\n"
+        "orc = oracle_from_product(idx, vs, lv)\n"
+        "for ef in (64, 68, 128):\n"
+        "    assert_search_equal(idx.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=8), 'generic ef=%%d' %% ef)\n"
+        "print('generic ok')\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HNSW_MI355X_LEAN="0"),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "generic ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
+def test_128d(kind):
+    """configs[3] dimension"""
+    idx, orc, qs = device_built(20000, 128, 16, kind)
+    for ef in (64, 128):
+        assert_search_equal(idx.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=8), "128d ef=%d" % ef)
+
+
+@pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
+def test_768d_unit_rows(kind):
+    """configs[2]: 768d, unit-normalised rows, efSearch = 128"""
+    idx, orc, qs = device_built(20000, 768, 16, kind, unit=True)
+    for ef in (64, 128):
+        assert_search_equal(idx.search_batch(qs[:64], 10, ef), orc.search_batch(qs[:64], 10, ef, nthreads=8),
+                            "768d ef=%d" % ef)
+
+
+@pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
+def test_device_build_at_256d(kind):
+    """configs[4] dimension: the on-device build, judged by recall and graph invariants; the search on the
+    graph it built is still the reference's search"""
+    idx, orc, qs = device_built(20000, 256, 16, kind)
+    assert idx.assert_param_compliance()
+    truth, _ = idx.brute_force(qs, 10)
+    got = idx.search_batch(qs, 10, 96)
+    rec = sum(len(set(a) & set(b)) for a, b in zip(got[0].tolist(), truth.tolist())) / (len(qs) * 10)
+    assert rec > 0.97, rec
+    assert_search_equal(got, orc.search_batch(qs, 10, 96, nthreads=8), "256d")
+
+
+def _sharded_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import hnsw_rs_amd as HH
+    n, d, m = 12000, 256, 16
+    vs = HH.synth_rows(0, 0x5EED0001, 0, n, d)
+    idx = HH.HNSW.new(m, 32, d)
+    idx.insert_bulk_sharded(vs, 4, False, levels=HH.draw_levels(m, n))
+    out = {}
+    for layer in idx.iter_layers():
+        ids, offs, nbrs = layer.csr()
+        out["offs%d" % layer.level] = offs
+        out["nbrs%d" % layer.level] = np.concatenate([np.sort(nbrs[int(offs[k]):int(offs[k + 1])]) for k in range(len(ids))])
+    qs = HH.synth_rows(0, 0x5EED0002, 0, 64, d)
+    truth, _ = idx.brute_force(qs, 10)
+    got, _, _, _ = idx.search_batch(qs, 10, 96)
+    out["recall"] = np.array([sum(len(set(a) & set(b)) for a, b in zip(got.tolist(), truth.tolist())) / 640.0])
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_device_build_at_256d(tmp_path):
+    """configs[4]: points sharded over two ranks, edge records all-gathered per batch; both replicas end
+    identical (two ranks on this one GPU, gloo rendezvous: only the exchange differs from an 8-GPU run)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), k
+    assert r0["recall"][0] > 0.97
