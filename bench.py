@@ -352,7 +352,7 @@ def main():
         ef = int(t.item())
     local_search = make_device_search(index, n, ef, B, dev)
     G = 8  # steps per exchange group (bucketed collectives)
-    pipe = PipelinedShardedSearch(index, d, n, ef, B, dev, group_steps=G) if use_dist else None
+    pipe = PipelinedShardedSearch.from_index(index, d, n, ef, B, dev, group_steps=G) if use_dist else None
     K, W = args.steps, args.warmup
 
     def run_dist(first, count):

@@ -72,6 +72,7 @@ SYMBOLS = {
     "hnsw_search_batch": (C.c_int, [vp, f32p, C.c_uint64, C.c_uint32, C.c_uint32, u32p, f32p, u32p,
                                     C.POINTER(QueryStats)]),
     "hnsw_search_batch_device": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]),
+    "hnsw_search_batch_device_finish": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]),
     "hnsw_distance_batch": (C.c_int, [vp, f32p, u32p, C.c_uint64, f32p]),
     "hnsw_search_layer": (C.c_int, [vp, C.c_uint32, f32p, u32p, C.c_uint32, C.c_uint32, u32p, f32p, u32p,
                                     C.POINTER(QueryStats)]),

@@ -974,6 +974,54 @@ int hnsw_search_batch_device(hnsw_index *h, const float *d_Q, uint64_t nq, uint3
     return hx::launch_search(h->dev.view, a, (uint32_t)nq, 0, static_cast<hipStream_t>(stream));
 }
 
+// Completes a hnsw_search_batch_device call: waits for the stream, reads the per-query statuses, re-runs
+// the queries whose visited table filled up with a table twice the size (same arithmetic, same result as
+// if the larger table had been used from the start) and reports the first remaining per-query error.
+int hnsw_search_batch_device_finish(hnsw_index *h, const float *d_Q, uint64_t nq, uint32_t n, uint32_t ef,
+                                    uint32_t *d_ids, float *d_dists, uint32_t *d_counts,
+                                    hnsw_query_stats *d_stats, void *stream_v) {
+    int rc = check_search_args(h, ef);
+    if (rc != HNSW_OK) return rc;
+    if (nq == 0 || n == 0) return HNSW_OK;
+    if (!d_Q || !d_ids || !d_stats || nq > 0x7FFFFFFFull) return HNSW_ERR_ARG;
+    rc = ensure_uploaded(h);
+    if (rc != HNSW_OK) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    const hx::DevView &v = h->dev.view;
+    const size_t st_bytes = nq * sizeof(hnsw_query_stats);
+    ScratchLease lease(h);
+    if ((rc = lease.prepare(h->dev.device, align256(nq * 4), st_bytes))) return rc;
+    SearchScratch &s = *lease.s;
+    hnsw_query_stats *st = static_cast<hnsw_query_stats *>(s.pin);
+    hx::SearchArgs a = ann_args(v, d_Q, n, ef, d_ids, d_dists, d_counts, d_stats);
+    uint32_t slots = hx::default_slots_log2(ef, v.S0);
+    std::vector<uint32_t> sel;
+    while (true) {
+        HIP_TRY(hipMemcpyAsync(st, d_stats, st_bytes, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        sel.clear();
+        for (uint64_t i = 0; i < nq; i++)
+            if (st[i].status == HNSW_ERR_OVERFLOW) sel.push_back((uint32_t)i);
+        if (sel.empty() || slots >= hx::max_slots_log2(ef)) break;
+        slots++;
+        HIP_TRY(hipMemcpyAsync(s.dev, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));  // `sel` is reused by the next round
+        a.qsel = static_cast<const uint32_t *>(s.dev);
+        rc = hx::launch_search(v, a, (uint32_t)sel.size(), slots, stream);
+        if (rc != HNSW_OK) return rc;
+    }
+    for (uint64_t i = 0; i < nq; i++) {
+        if (st[i].status != HNSW_OK) {
+            set_error("query %llu failed with status %d%s", (unsigned long long)i, st[i].status,
+                      st[i].status == HNSW_ERR_NAN_INPUT    ? " (NaN in the query or in a distance)"
+                      : st[i].status == HNSW_ERR_OVERFLOW   ? " (visited table exhausted at its largest size)"
+                                                             : "");
+            return st[i].status;
+        }
+    }
+    return HNSW_OK;
+}
+
 int hnsw_distance_batch(hnsw_index *h, const float *q, const uint32_t *ids, uint64_t k, float *out) {
     int rc = check_search_args(h, 1);
     if (rc != HNSW_OK) return rc;

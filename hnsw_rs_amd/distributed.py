@@ -69,23 +69,90 @@ class ShardedSearcher:
 
 def make_device_search(index, n, ef, max_queries, device):
     """local_search closure over the HIP path: device pointers in, device tensors out, enqueued on
-    torch's current stream (no host synchronisation)."""
+    torch's current stream (no host synchronisation).  `local_search.check()` completes the last call:
+    it synchronises, re-runs queries whose visited table overflowed and raises the first per-query error
+    (hnsw_search_batch_device_finish)."""
     ids = torch.empty((max_queries, n), dtype=torch.int32, device=device)
     dists = torch.empty((max_queries, n), dtype=torch.float32, device=device)
     counts = torch.empty(max_queries, dtype=torch.int32, device=device)
     stats = torch.empty((max_queries, 4), dtype=torch.int32, device=device)
+    last = {}
 
     def local_search(Q):
         nq = Q.shape[0]
         assert nq <= max_queries and Q.is_contiguous() and Q.dtype == torch.float32
+        stream = torch.cuda.current_stream().cuda_stream
         index.search_batch_device(Q.data_ptr(), nq, n, ef, ids.data_ptr(), dists.data_ptr(),
-                                  counts.data_ptr(), stats.data_ptr(),
-                                  torch.cuda.current_stream().cuda_stream)
+                                  counts.data_ptr(), stats.data_ptr(), stream)
+        last["call"] = (Q, nq, stream)
         return ids[:nq], dists[:nq]
 
+    def check():
+        Q, nq, stream = last["call"]
+        index.search_batch_device_finish(Q.data_ptr(), nq, n, ef, ids.data_ptr(), dists.data_ptr(),
+                                         counts.data_ptr(), stats.data_ptr(), stream)
+        return ids[:nq], dists[:nq]
+
+    local_search.check = check
     local_search.stats = stats
     local_search.counts = counts
     return local_search
+
+
+class CudaLanes:
+    """The two lanes of the pipeline as HIP streams (torch's stream objects on ROCm)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.compute = torch.cuda.current_stream(device)
+        self.comm = torch.cuda.Stream(device=device)
+
+    def event(self):
+        return torch.cuda.Event()
+
+    def on(self, lane):
+        return torch.cuda.stream(lane)
+
+    def wait(self, lane, ev):
+        lane.wait_event(ev)
+
+    def record(self, lane, ev):
+        ev.record(lane)
+
+    def drain(self):
+        self.comm.synchronize()
+        self.compute.synchronize()
+
+
+class InlineLanes:
+    """Everything runs at once on the caller's thread (CPU tensors, gloo): the tests' stand-in for the
+    stream pair, which keeps the grouping / bucketing / status logic identical."""
+
+    class _Nothing:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    def __init__(self, device=None):
+        self.device = device
+        self.compute = self.comm = None
+
+    def event(self):
+        return None
+
+    def on(self, lane):
+        return InlineLanes._Nothing()
+
+    def wait(self, lane, ev):
+        pass
+
+    def record(self, lane, ev):
+        pass
+
+    def drain(self):
+        pass
 
 
 class PipelinedShardedSearch:
@@ -99,33 +166,49 @@ class PipelinedShardedSearch:
         compute:             search x8 (g0)          search x8 (g1)        ...
 
     ids and dists travel in ONE gather (a [G, 2, s, n] int32 buffer: ids, then the distance bits).
+    Every step has its own statistics buffer; the number of queries of a group that did not finish with
+    status 0 (visited table overflow, NaN) travels back with the results, and the root raises on the first
+    group that reports any -- a failed query never comes back as a row of padding ids.
     `submit(Q_root, g)` enqueues a group of g steps; `results(k)` (root only) returns the group's
-    outputs, valid until `depth` more groups have been submitted; `finish()` drains everything."""
+    outputs, valid until `depth` more groups have been submitted; `finish()` drains everything and raises
+    if any query of any group failed.
 
-    def __init__(self, index, dim, n, ef, shard, device, group_steps=8, depth=2, group=None, root=0):
-        self.index, self.dim, self.n, self.ef, self.s = index, dim, n, ef, shard
+    search_step(q [s, dim], ids_out [s, n] int32, dist_bits_out [s, n] int32, stats_out [s, 4] int32, lane)
+    enqueues one search on `lane`; `from_index` wraps the HIP path."""
+
+    def __init__(self, search_step, dim, n, shard, device, group_steps=8, depth=2, group=None, root=0, lanes=None):
+        self.search_step, self.dim, self.n, self.s = search_step, dim, n, shard
         self.device, self.group, self.root, self.depth, self.G = device, group, root, depth, group_steps
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.comm = torch.cuda.Stream(device=device)
-        self.compute = torch.cuda.current_stream(device)
+        self.lanes = lanes if lanes is not None else CudaLanes(device)
         W, s, G = self.world, shard, group_steps
         self.q = [torch.empty((G, s, dim), dtype=torch.float32, device=device) for _ in range(depth)]
-        self.res = [torch.empty((G, 2, s, n), dtype=torch.int32, device=device) for _ in range(depth)]
-        self.counts = torch.empty(s, dtype=torch.int32, device=device)
-        self.stats = torch.empty((s, 4), dtype=torch.int32, device=device)
-        self.out = ([torch.empty((W, G, 2, s, n), dtype=torch.int32, device=device) for _ in range(depth)]
+        # [G + 1, 2, s, n]: G steps of (ids, distance bits) and one trailing record whose first word is the
+        # number of failed queries of the group
+        self.res = [torch.zeros((G + 1, 2, s, n), dtype=torch.int32, device=device) for _ in range(depth)]
+        self.stats = [torch.zeros((G, s, 4), dtype=torch.int32, device=device) for _ in range(depth)]
+        self.out = ([torch.zeros((W, G + 1, 2, s, n), dtype=torch.int32, device=device) for _ in range(depth)]
                     if self.rank == root else None)
-        self.ev_q = [torch.cuda.Event() for _ in range(depth)]
-        self.ev_r = [torch.cuda.Event() for _ in range(depth)]
-        self.ev_g = [torch.cuda.Event() for _ in range(depth)]
+        self.ev_q = [self.lanes.event() for _ in range(depth)]
+        self.ev_r = [self.lanes.event() for _ in range(depth)]
+        self.ev_g = [self.lanes.event() for _ in range(depth)]
         self.pending = None  # (group index, steps) whose gather has not been enqueued yet
+        self.gathered = []   # groups gathered but not yet checked: (group index, steps)
         self.n_groups = 0
+
+    @staticmethod
+    def from_index(index, dim, n, ef, shard, device, **kw):
+        def step(q, ids_out, bits_out, stats_out, lane):
+            index.search_batch_device(q.data_ptr(), q.shape[0], n, ef, ids_out.data_ptr(), bits_out.data_ptr(),
+                                      0, stats_out.data_ptr(), lane.cuda_stream)
+        return PipelinedShardedSearch(step, dim, n, shard, device, **kw)
 
     def _scatter(self, k, Q_root, g):
         b = k % self.depth
-        with torch.cuda.stream(self.comm):
-            self.comm.wait_event(self.ev_r[b])  # the searches that last read q[b] are done
+        L = self.lanes
+        with L.on(L.comm):
+            L.wait(L.comm, self.ev_r[b])  # the searches that last read q[b] are done
             dst = self.q[b][:g]
             if self.rank == self.root:
                 # Q_root: [g, world * s, dim] -> per rank [g, s, dim]
@@ -133,35 +216,54 @@ class PipelinedShardedSearch:
                 dist.scatter(dst, chunks, src=self.root, group=self.group)
             else:
                 dist.scatter(dst, None, src=self.root, group=self.group)
-            self.ev_q[b].record(self.comm)
+            L.record(L.comm, self.ev_q[b])
 
     def _search(self, k, g):
         b = k % self.depth
-        self.compute.wait_event(self.ev_q[b])
-        self.compute.wait_event(self.ev_g[b])  # the gather that last read res[b] is done
-        for j in range(g):
-            r = self.res[b][j]
-            self.index.search_batch_device(self.q[b][j].data_ptr(), self.s, self.n, self.ef,
-                                           r[0].data_ptr(), r[1].data_ptr(), self.counts.data_ptr(),
-                                           self.stats.data_ptr(), self.compute.cuda_stream)
-        self.ev_r[b].record(self.compute)
+        L = self.lanes
+        L.wait(L.compute, self.ev_q[b])
+        L.wait(L.compute, self.ev_g[b])  # the gather that last read res[b] is done
+        with L.on(L.compute):
+            for j in range(g):
+                r = self.res[b][j]
+                self.search_step(self.q[b][j], r[0], r[1], self.stats[b][j], L.compute)
+            # failed queries of the group, on the device, next to the results
+            bad = (self.stats[b][:g, :, 3] != 0).sum().to(torch.int32)
+            self.res[b][self.G].view(-1)[0:1].copy_(bad.view(1))
+        L.record(L.compute, self.ev_r[b])
 
     def _gather(self, k, g):
         b = k % self.depth
-        with torch.cuda.stream(self.comm):
-            self.comm.wait_event(self.ev_r[b])
-            src = self.res[b][:g]
+        L = self.lanes
+        with L.on(L.comm):
+            L.wait(L.comm, self.ev_r[b])
+            src = self.res[b]
             if self.rank == self.root:
-                dist.gather(src, [o[:g] for o in self.out[b].unbind(0)], dst=self.root, group=self.group)
+                dist.gather(src, list(self.out[b].unbind(0)), dst=self.root, group=self.group)
             else:
                 dist.gather(src, None, dst=self.root, group=self.group)
-            self.ev_g[b].record(self.comm)
+            L.record(L.comm, self.ev_g[b])
+        self.gathered.append((k, g))
+
+    def _check(self, keep_last=0):
+        """root: raise if a gathered group reports failed queries (reads one word per rank and group)"""
+        while len(self.gathered) > keep_last:
+            k, g = self.gathered.pop(0)
+            if self.rank != self.root:
+                continue
+            if self.ev_g[k % self.depth] is not None:
+                self.ev_g[k % self.depth].synchronize()
+            bad = self.out[k % self.depth][:, self.G].reshape(self.world, -1)[:, 0].cpu()
+            if int(bad.sum()) != 0:
+                raise RuntimeError("group %d: %s queries per rank did not finish with status 0 (visited table "
+                                   "overflow or NaN); re-run them through hnsw_search_batch" % (k, bad.tolist()))
 
     def submit(self, Q_root, g):
         """Q_root: [g, world * shard, dim] on the root (None elsewhere), 1 <= g <= group_steps."""
         assert 1 <= g <= self.G
         k = self.n_groups
         self.n_groups += 1
+        self._check(keep_last=1)  # the buffers of group k - depth are about to be reused
         self._scatter(k, Q_root, g)
         if self.pending is not None:
             self._gather(*self.pending)
@@ -173,8 +275,8 @@ class PipelinedShardedSearch:
         if self.pending is not None:
             self._gather(*self.pending)
             self.pending = None
-        self.comm.synchronize()
-        self.compute.synchronize()
+        self.lanes.drain()
+        self._check()
 
     def results(self, k, j):
         """(ids [W*s, n] int32, dists [W*s, n] f32) of step j of group k, on the root"""

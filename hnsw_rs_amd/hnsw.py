@@ -265,6 +265,12 @@ class HNSW:
         check(self._L.hnsw_search_batch_device(self._h, d_Q, nq, n, ef, d_ids, d_dists, d_counts, d_stats,
                                                stream))
 
+    def search_batch_device_finish(self, d_Q, nq, n, ef, d_ids, d_dists, d_counts, d_stats, stream=0):
+        """Completes search_batch_device: synchronises, re-runs queries whose visited table overflowed,
+        raises the first per-query error."""
+        check(self._L.hnsw_search_batch_device_finish(self._h, d_Q, nq, n, ef, d_ids, d_dists, d_counts, d_stats,
+                                                      stream))
+
     def distance_batch(self, q, ids):
         """VecBase::dist2many seam on the device"""
         q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1)

@@ -159,6 +159,16 @@ int hnsw_search_batch_device(hnsw_index *h, const float *d_Q, uint64_t nq, uint3
                              uint32_t *d_ids, float *d_dists, uint32_t *d_counts,
                              hnsw_query_stats *d_stats, void *stream);
 
+/* Completes a hnsw_search_batch_device call (same arguments): waits for `stream`, reads the per-query
+ * statuses, re-runs the queries whose visited table filled up with a larger table (the results are those a
+ * larger table would have given from the start) and returns the first remaining per-query error -- the
+ * error behaviour of the reference's `Result` (template.rs:306, 323) for callers that keep everything in
+ * HBM.  The device entry above never synchronises; a caller that skips this call must inspect
+ * d_stats[i].status itself. */
+int hnsw_search_batch_device_finish(hnsw_index *h, const float *d_Q, uint64_t nq, uint32_t n, uint32_t ef,
+                                    uint32_t *d_ids, float *d_dists, uint32_t *d_counts,
+                                    hnsw_query_stats *d_stats, void *stream);
+
 /* Test seams that mirror the reference's own units:
  * VecBase::dist2many (vectors/src/lib.rs:17-22): the query (quantised like ann_by_vector does,
  * template.rs:313) against stored ids, on the device, exact accumulation order. */

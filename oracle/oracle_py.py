@@ -269,6 +269,9 @@ class OracleHNSW:
         deg = self.L.orc_neighbors(self.h, layer, int(node), _p(buf, u32p), buf.shape[0])
         if deg < 0:
             raise KeyError(node)
+        if deg > buf.shape[0]:  # a hub: ask again with room for the whole row
+            buf = np.zeros(int(deg), dtype=np.uint32)
+            deg = self.L.orc_neighbors(self.h, layer, int(node), _p(buf, u32p), buf.shape[0])
         return buf[:deg].copy()
 
     def layer_csr(self, layer):

@@ -70,3 +70,69 @@ def test_shard_bounds_cover_the_batch():
                 cover += list(range(lo, hi))
                 assert hi - lo <= shard_size(nq, w)
             assert cover == list(range(nq))
+
+
+def _pipe_worker(rank, world, port, outfile, inject_failure):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hnsw_rs_amd.distributed import InlineLanes, PipelinedShardedSearch
+    from oracle import oracle_py as O
+    from tests.util import rand_vectors
+    n, d, m, k, ef, shard, G = 600, 10, 8, 5, 16, 7, 2
+    vs = rand_vectors(n, d, 1)
+    orc = O.OracleHNSW(m, None, d).insert_bulk(vs, O.draw_levels(n, m, 1))
+
+    calls = {"n": 0}
+
+    def search_step(q, ids_out, bits_out, stats_out, lane):
+        ids, dists, _, st = orc.search_batch(q.numpy(), k, ef)
+        ids_out.copy_(torch.from_numpy(ids.astype(np.int64)).to(torch.int32))
+        bits_out.copy_(torch.from_numpy(dists.view(np.int32).copy()))
+        stats_out.zero_()
+        stats_out[:, :3] = torch.from_numpy(st.astype(np.int64)).to(torch.int32)
+        calls["n"] += 1
+        if inject_failure and rank == 1 and calls["n"] == 3:
+            stats_out[2, 3] = -7  # one query of one step on the non-root rank reports an overflow
+
+    pipe = PipelinedShardedSearch(search_step, d, k, shard, torch.device("cpu"), group_steps=G, depth=2,
+                                  lanes=InlineLanes())
+    steps = 5  # groups of 2, 2 and 1 steps: the last group is a partial one
+    Q = torch.from_numpy(rand_vectors(steps * world * shard, d, 2)).view(steps, world * shard, d)
+    got, failed = {}, ""
+    try:
+        i = 0
+        while i < steps:
+            g = min(G, steps - i)
+            kk = pipe.submit(Q[i:i + g].contiguous() if rank == 0 else None, g)
+            if rank == 0 and kk >= 1:  # results of the group before stay valid until `depth` more submits
+                pass
+            i += g
+        pipe.finish()
+    except RuntimeError as e:
+        failed = str(e)
+    if rank == 0:
+        ok = True
+        if not inject_failure:
+            # the last `depth` groups are still held: check them against a direct search
+            for kk, first, g in ((1, 2, 2), (2, 4, 1)):
+                for j in range(g):
+                    ids, dists = pipe.results(kk, j)
+                    w_ids, w_d, _, _ = orc.search_batch(Q[first + j].numpy(), k, ef)
+                    ok &= np.array_equal(ids.numpy().astype(np.uint32), w_ids) and np.array_equal(dists.numpy(), w_d)
+            ok &= failed == ""
+        else:
+            ok = "did not finish with status 0" in failed
+        open(outfile, "w").write("ok" if ok else "mismatch: " + failed)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("inject_failure", [False, True])
+def test_pipelined_bucketed_exchange_world_size_2_gloo(tmp_path, inject_failure):
+    """the N > 1 bench path (groups of steps, one scatter and one gather per group, a partial last group)
+    with the stream pair replaced by an inline executor; a failed query on a non-root rank must surface"""
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_pipe_worker, args=(2, _free_port(), out, inject_failure), nprocs=2, join=True)
+    assert open(out).read() == "ok"

@@ -285,6 +285,55 @@ def test_device_pointer_entry_point(synth20k):
 
 
 @pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
+def test_device_pointer_entry_recovers_from_a_full_visited_table(kind):
+    """a hub with 5000 neighbours fills the default 4096-slot visited table: the device entry flags the
+    query (status OVERFLOW, never a row of made-up ids), hnsw_search_batch_device_finish re-runs it with a
+    larger table and the answer is the oracle's"""
+    import torch
+    n, d, m = 9000, 100 if kind == H.VEC_F32 else 12, 4
+    vs, qs = rand_vectors(n, d, 13), rand_vectors(24, d, 14)
+    lv = O.draw_levels(n, m, 3)
+    orc = O.OracleHNSW(m, None, d, kind).insert_bulk(vs, lv)
+    ids, offs, nbrs = orc.layer_csr(0)
+    adj = {int(i): set(int(x) for x in nbrs[int(offs[k]):int(offs[k + 1])]) for k, i in enumerate(ids)}
+    for t in range(100, 5100):
+        adj[5].add(t)
+        adj[t].add(5)
+    rows = [sorted(adj[int(i)]) for i in ids]
+    orc2 = O.OracleHNSW(m, None, d, kind)
+    orc2.import_points(vs, lv)
+    orc2.import_layer(0, ids, np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64),
+                      np.concatenate([np.array(r, dtype=np.uint32) for r in rows]))
+    for l in range(1, orc.nb_layers):
+        orc2.import_layer(l, *orc.layer_csr(l))
+    orc2.set_ep(orc.ep)
+    index = product_from_oracle(orc2, vs, lv)
+    index.upload()
+    qs[0] = vs[5]  # this query certainly expands the hub
+    nq, topn, ef = qs.shape[0], 10, 32
+    dev = torch.device("cuda:0")
+    dQ = torch.from_numpy(qs).to(dev)
+    d_ids = torch.empty((nq, topn), dtype=torch.int32, device=dev)
+    d_dists = torch.empty((nq, topn), dtype=torch.float32, device=dev)
+    d_counts = torch.empty(nq, dtype=torch.int32, device=dev)
+    d_stats = torch.empty((nq, 4), dtype=torch.int32, device=dev)
+    args = (dQ.data_ptr(), nq, topn, ef, d_ids.data_ptr(), d_dists.data_ptr(), d_counts.data_ptr(), d_stats.data_ptr(), 0)
+    index.search_batch_device(*args)
+    torch.cuda.synchronize()
+    st = d_stats.cpu().numpy()
+    assert st[0, 3] == _lib.ERR_OVERFLOW, st[:3]
+    assert (d_ids.cpu().numpy().view(np.uint32)[st[:, 3] != 0] == O.UINT32_MAX).all()
+    index.search_batch_device_finish(*args)
+    want = orc2.search_batch(qs, topn, ef)
+    got = (d_ids.cpu().numpy().view(np.uint32), d_dists.cpu().numpy(), d_counts.cpu().numpy().view(np.uint32),
+           d_stats.cpu().numpy().astype(np.int64))
+    assert (got[3][:, 3] == 0).all()
+    assert_search_equal(got, want, "after finish")
+    # the host-pointer entry does the same by itself
+    assert_search_equal(index.search_batch(qs, topn, ef), want, "host entry")
+
+
+@pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
 @pytest.mark.parametrize("m", [24, 32, 48])
 def test_wide_adjacency_rows(kind, m):
     """m > 16: layer-0 rows of 64 / 128 slots are walked in several passes"""
