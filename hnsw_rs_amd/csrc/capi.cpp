@@ -41,6 +41,10 @@ struct hnsw_index {
     hx::DeviceIndex dev;
     int device = -1;
     int gpu_build = 0;  // option "gpu_build": insert_bulk runs the on-device build (1 host connect, 2 device connect)
+    // set when an on-device build stopped half way (HIP error, failed exchange): the new points are stored
+    // but not all of them are connected, so every later search or build on this handle fails loudly
+    // instead of answering from an incomplete graph
+    bool incomplete_build = false;
     std::mutex mu;
     std::mutex pool_mu;
     std::vector<std::unique_ptr<SearchScratch>> pool;
@@ -90,6 +94,10 @@ int ensure_uploaded(hnsw_index *h) {
 int check_search_args(const hnsw_index *h, uint32_t ef) {
     if (!h) {
         set_error("null handle");
+        return HNSW_ERR_ARG;
+    }
+    if (h->incomplete_build) {
+        set_error("an on-device build on this handle failed half way; the index is incomplete, discard it");
         return HNSW_ERR_ARG;
     }
     if (h->host->len() == 0) {
@@ -375,7 +383,7 @@ int gpu_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_th
                         if (id != UINT32_MAX) nbrs[l].push_back(hx::Dist{id, o_d[(i * L + l) * m + k]});
                     }
                 }
-                const int r = host.connect_point(p, nbrs, &dirty_t[t]);
+                const int r = host.connect_point(p, nbrs, &dirty_t[t], &stamps);
                 if (r != HNSW_OK) err.store(r);
             }
         };
@@ -395,7 +403,7 @@ int gpu_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_th
             std::sort(fallback.begin(), fallback.end());
             std::unique_ptr<hx::Inserter, void (*)(hx::Inserter *)> ins(hx::new_inserter(host.len()),
                                                                          hx::free_inserter);
-            hx::DirtyScope scope(&dirty_t[0]);
+            hx::DirtyScope scope(&dirty_t[0], &stamps);
             for (NodeID p : fallback) {
                 rc = host.insert(p, *ins);
                 if (rc != HNSW_OK) return rc;
@@ -601,7 +609,27 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     const uint32_t BMAX = SH_BCAP;
     // a point has 1 + 1/(m-1) layers on average; sharded: records in both directions
     const uint32_t W = sh ? sh->world : 1, SLOT_REC = sh ? shard_slot_records(m, W) : 0;
-    const uint32_t REQ_CAP = sh ? W * SLOT_REC : BMAX * m * 2;
+    // Record capacity: what the largest batch of this build can file, (level + 1) * m per point (twice
+    // that with records in both directions) -- not an average: a batch of high-level points files more than
+    // 2 m each.  Sharded: the caller's slots are sized by m and the world alone; a point whose records do
+    // not fit its rank's slot fails cleanly on the device (nothing reserved) and takes the CPU path.
+    uint64_t need_max = 0;
+    if (!sh) {
+        uint64_t c = n_before + pos;
+        for (size_t q = pos; q < order.size();) {
+            const size_t Bq = std::min<size_t>(order.size() - q, std::min<uint64_t>(BMAX, std::max<uint64_t>(64, c / 8)));
+            uint64_t need = 0;
+            for (size_t i = 0; i < Bq; i++) need += ((uint64_t)host.levels[order[q + i]] + 1) * m;
+            need_max = std::max(need_max, need);
+            q += Bq;
+            c += Bq;
+        }
+        if (need_max >= (1ull << 31)) {
+            set_error("on-device build: a batch would file %llu edge records", (unsigned long long)need_max);
+            return HNSW_ERR_ARG;
+        }
+    }
+    const uint32_t REQ_CAP = sh ? W * SLOT_REC : (uint32_t)std::max<uint64_t>(need_max, (uint64_t)BMAX * m * 2);
     if (sh && (sh->slot_bytes < shard_slot_bytes(m, W) || sh->rank >= W || !sh->d_send || !sh->d_recv || !sh->allgather)) {
         set_error("sharded build: exchange buffers too small or bad rank / world");
         return HNSW_ERR_ARG;
@@ -660,7 +688,11 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
             HIP_TRY(hipMemcpy(o_st.data(), dStatus.p, nb * 4, hipMemcpyDeviceToHost));
             for (size_t i = 0; i < nb; i++)
                 if (o_st[i] != HNSW_OK) failed.push_back(batch[i]);  // filed nothing; CPU path after the build
-            nreq = std::min<uint32_t>(counts[0], REQ_CAP);
+            nreq = counts[0];  // reservations that fit, nothing else (hx_insert_kernel)
+            if (nreq > REQ_CAP) {
+                set_error("on-device build: record counter %u beyond the capacity %u", nreq, REQ_CAP);
+                return HNSW_ERR_OVERFLOW;
+            }
         } else {
             // the slot: [count, nfail, ...64 B][failed ids][keys][vals]
             unsigned char *slot = sh->d_send;
@@ -835,6 +867,17 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     return HNSW_OK;
 }
 
+// An on-device build that returns an error after it stored the points leaves some of them unconnected
+// (and, in the device-connect form, the graph only in HBM): the handle is marked and refuses further use.
+// Errors raised before anything was stored (bad rows, bad arguments) leave the index as it was.
+template <class F>
+int device_build_guard(hnsw_index *h, F &&build) {
+    const uint64_t n_before = h->host->len();
+    const int rc = build();
+    if (rc != HNSW_OK && h->host->len() != n_before) h->incomplete_build = true;
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -897,8 +940,9 @@ int hnsw_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_t
 int hnsw_insert_bulk_levels(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads,
                             int verbose, const uint8_t *levels) {
     if (!h || !rows) return HNSW_ERR_ARG;
-    if (h->gpu_build == 2) return gpu_insert_bulk_full(h, rows, n, nb_threads, verbose, levels);
-    if (h->gpu_build) return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels);
+    if (h->incomplete_build) return check_search_args(h, 1);
+    if (h->gpu_build == 2) return device_build_guard(h, [&] { return gpu_insert_bulk_full(h, rows, n, nb_threads, verbose, levels); });
+    if (h->gpu_build) return device_build_guard(h, [&] { return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels); });
     return h->host->insert_bulk(rows, n, nb_threads, verbose != 0, levels);
 }
 uint64_t hnsw_sharded_slot_bytes(const hnsw_index *h, uint32_t world) {
@@ -911,13 +955,15 @@ int hnsw_insert_bulk_sharded(hnsw_index *h, const float *rows, uint64_t n, uint3
     if (!h || !rows || world == 0 || rank >= world) return HNSW_ERR_ARG;
     ShardCtx sh{rank, world, static_cast<unsigned char *>(d_send), static_cast<unsigned char *>(d_recv), slot_bytes,
                 allgather, ctx};
-    return gpu_insert_bulk_full(h, rows, n, nb_threads, verbose, levels, &sh);
+    if (h->incomplete_build) return check_search_args(h, 1);
+    return device_build_guard(h, [&] { return gpu_insert_bulk_full(h, rows, n, nb_threads, verbose, levels, &sh); });
 }
 int hnsw_insert_bulk_device(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads,
                             int verbose, const uint8_t *levels) {
     if (!h || !rows) return HNSW_ERR_ARG;
-    if (h->gpu_build == 1) return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels);
-    return gpu_insert_bulk_full(h, rows, n, nb_threads, verbose, levels);
+    if (h->incomplete_build) return check_search_args(h, 1);
+    if (h->gpu_build == 1) return device_build_guard(h, [&] { return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels); });
+    return device_build_guard(h, [&] { return gpu_insert_bulk_full(h, rows, n, nb_threads, verbose, levels); });
 }
 int hnsw_insert_vec(hnsw_index *h, const float *v, uint32_t *out_id) {
     return hnsw_insert_vec_level(h, v, -1, out_id);

@@ -3,7 +3,7 @@
 // The build follows the reference's insertion algorithm step for step (citations inline) with
 // flat containers instead of BTreeSet / IntSet / IntMap: sorted vectors with set semantics,
 // epoch-stamped visited arrays, one spin lock per adjacency row.  With nb_threads == 1 the graph
-// it produces is a pure function of (vectors, levels) -- tests/test_build_parity.py checks it
+// it produces is a pure function of (vectors, levels) -- tests/test_host_build.py checks it
 // edge for edge against the CPU oracle's literal restatement.
 //
 // Float semantics: compiled with -ffp-contract=off, never fast-math; every op rounds once, in
@@ -213,14 +213,14 @@ bool HostIndex::degree(uint32_t layer, NodeID id, size_t *out) const {
 
 // rows touched by the current thread's connect_point (on-device build): layer << 32 | id.  A
 // per-row stamp (set with an atomic exchange) keeps every row at most once per batch across threads.
+// The stamps belong to ONE build (DirtyStamps, owned by the build that created it); a thread finds the
+// stamps of the build it works for through a thread-local pointer set together with its dirty list, so
+// two handles building at the same time never see each other's arrays.
 static thread_local std::vector<uint64_t> *tl_dirty = nullptr;
-static std::atomic<uint32_t> *g_stamp0 = nullptr, *g_stamp_up = nullptr;
-static uint32_t g_stamp_epoch = 0;
+static thread_local DirtyStamps *tl_stamps = nullptr;
 static inline void mark_dirty_row(uint32_t layer, NodeID id, size_t up_row) {
     if (!tl_dirty) return;
-    std::atomic<uint32_t> *st = layer == 0 ? (g_stamp0 ? &g_stamp0[id] : nullptr)
-                                           : (g_stamp_up ? &g_stamp_up[up_row] : nullptr);
-    if (st && st->exchange(g_stamp_epoch, std::memory_order_relaxed) == g_stamp_epoch) return;
+    if (tl_stamps && tl_stamps->seen(layer, layer == 0 ? (size_t)id : up_row)) return;
     tl_dirty->push_back(((uint64_t)layer << 32) | id);
 }
 #define mark_dirty(layer, id) mark_dirty_row(layer, id, (layer) == 0 ? 0 : (size_t)upper_base[id] + (layer) - 1)
@@ -575,23 +575,31 @@ Inserter *new_inserter(uint64_t n_points) {
     return ins;
 }
 void free_inserter(Inserter *ins) { delete ins; }
-DirtyScope::DirtyScope(std::vector<uint64_t> *dirty) { tl_dirty = dirty; }
-DirtyScope::~DirtyScope() { tl_dirty = nullptr; }
+DirtyScope::DirtyScope(std::vector<uint64_t> *dirty, DirtyStamps *stamps) {
+    tl_dirty = dirty;
+    tl_stamps = stamps;
+}
+DirtyScope::~DirtyScope() {
+    tl_dirty = nullptr;
+    tl_stamps = nullptr;
+}
 
-DirtyStamps::DirtyStamps(size_t n0, size_t n_up) {
+DirtyStamps::DirtyStamps(size_t n0, size_t n_up) : n0_(n0), nup_(n_up) {
     s0_.reset(new std::atomic<uint32_t>[n0 ? n0 : 1]);
     sup_.reset(new std::atomic<uint32_t>[n_up ? n_up : 1]);
     for (size_t i = 0; i < n0; i++) s0_[i].store(0, std::memory_order_relaxed);
     for (size_t i = 0; i < n_up; i++) sup_[i].store(0, std::memory_order_relaxed);
-    g_stamp0 = s0_.get();
-    g_stamp_up = sup_.get();
-    g_stamp_epoch = 0;
 }
-DirtyStamps::~DirtyStamps() { g_stamp0 = g_stamp_up = nullptr; }
-void DirtyStamps::next_batch() { g_stamp_epoch++; }
+DirtyStamps::~DirtyStamps() {}
+void DirtyStamps::next_batch() { epoch_++; }
+bool DirtyStamps::seen(uint32_t layer, size_t row) {
+    if (row >= (layer == 0 ? n0_ : nup_)) return false;  // a row added after the build began: always reported
+    std::atomic<uint32_t> &st = layer == 0 ? s0_[row] : sup_[row];
+    return st.exchange(epoch_, std::memory_order_relaxed) == epoch_;
+}
 
 int HostIndex::connect_point(NodeID point_id, const std::vector<std::vector<Dist>> &nbrs,
-                             std::vector<uint64_t> *dirty) {
+                             std::vector<uint64_t> *dirty, DirtyStamps *stamps) {
     if (point_id >= len()) return HNSW_ERR_ARG;
     Inserter ins;
     for (size_t l = 0; l < nbrs.size(); l++) {
@@ -600,10 +608,8 @@ int HostIndex::connect_point(NodeID point_id, const std::vector<std::vector<Dist
         std::sort(lr.nbrs.begin(), lr.nbrs.end(), dist_lt);  // BTreeSet<Dist> order
         ins.insertion_results[l] = std::move(lr);
     }
-    tl_dirty = dirty;
-    const int rc = apply_insertion_results(ins);
-    tl_dirty = nullptr;
-    return rc;
+    DirtyScope scope(dirty, stamps);
+    return apply_insertion_results(ins);
 }
 
 // HNSW::store_points, template.rs:269-293

@@ -111,7 +111,7 @@ class HostIndex {
     // the heuristic's selection for layer l (Dist of each neighbour to the point).  Rows touched are
     // appended to `dirty` (layer << 32 | id) when it is not null.
     int connect_point(NodeID point_id, const std::vector<std::vector<Dist>> &nbrs,
-                      std::vector<uint64_t> *dirty);
+                      std::vector<uint64_t> *dirty = nullptr, class DirtyStamps *stamps = nullptr);
     void prepare_build() { ensure_locks(); }
     int insert_bulk(const float *rows, uint64_t n, uint32_t nb_threads, bool verbose,
                     const uint8_t *levels_in);
@@ -137,20 +137,25 @@ class HostIndex {
 Inserter *new_inserter(uint64_t n_points);
 void free_inserter(Inserter *);
 // routes the rows touched by this thread's add_edge / remove_edge into `dirty` while in scope
+class DirtyStamps;
 struct DirtyScope {
-    explicit DirtyScope(std::vector<uint64_t> *dirty);
+    explicit DirtyScope(std::vector<uint64_t> *dirty, DirtyStamps *stamps = nullptr);
     ~DirtyScope();
 };
 
-// one per on-device build: a stamp per adjacency row so that a row is reported dirty once per batch
+// one per on-device build (owned by that build, reached by its threads through DirtyScope): a stamp per
+// adjacency row so that a row is reported dirty once per batch
 class DirtyStamps {
   public:
     DirtyStamps(size_t n_rows0, size_t n_rows_up);
     ~DirtyStamps();
     void next_batch();
+    bool seen(uint32_t layer, size_t row);  // true when the row was already reported in this batch
 
   private:
     std::unique_ptr<std::atomic<uint32_t>[]> s0_, sup_;
+    size_t n0_, nup_;
+    uint32_t epoch_ = 1;
 };
 
 // persistence (template.rs:43-131)

@@ -2304,11 +2304,25 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
         // to (layer, n <- p) -- so that the record list alone carries the whole batch to every replica
         const uint32_t per_edge = a.emit_own ? 2u : 1u;
         total *= per_edge;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(a.req_count, total);
+        // Reserve `total` record slots.  The counter only ever moves by reservations that fit (compare
+        // and swap): after the kernel it is exactly the number of records written, so the host never
+        // sorts or applies a slot nobody filled (an add-then-check would leave the counter beyond the
+        // last good record whenever a reservation fails).
+        uint32_t base = 0xFFFFFFFFu;
+        if (lane == 0) {
+            uint32_t cur = __hip_atomic_load(a.req_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((uint64_t)cur + total <= a.req_cap) {
+                const uint32_t seen = atomicCAS(a.req_count, cur, cur + total);
+                if (seen == cur) {
+                    base = cur;
+                    break;
+                }
+                cur = seen;
+            }
+        }
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (base + total > a.req_cap) {
-            status = HNSW_ERR_OVERFLOW;  // nothing written: the point takes the CPU path
+        if (base == 0xFFFFFFFFu) {
+            status = HNSW_ERR_OVERFLOW;  // nothing written, nothing reserved: the point takes the CPU path
         } else {
             for (uint32_t l = 0; l <= level; l++) {
                 const uint32_t S = l == 0 ? v.S0 : v.S1;
