@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec of the HNSW search hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`python bench.py --gpus N` with N > 1 and no launcher environment starts the N ranks itself (one process
+per GPU, before anything touches a GPU) and fails if the node has fewer GPUs; under a launcher it fails
+when WORLD_SIZE is not N.  `n_gpus` in the JSON line is the size of the RCCL communicator.
 
 Workload (BASELINE.json configs[1]: "1M x 100d fp32 L2, M=16 efSearch=64, batch=1024 queries"):
 N = 1M x 100d synthetic GloVe-shaped vectors (recipe A of SURVEY.md section 8d), M = 16,
@@ -35,6 +39,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming)
+
+
+def kernel_sources_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("search_kernels.hip", "search_lean.hip", "device_index.h"):
+        h.update(open(os.path.join(ROOT, "hnsw_rs_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 EF_LADDER = (64, 68, 72, 76, 80, 88, 96, 112, 128, 160, 192, 256)
 
 
@@ -72,11 +84,80 @@ def parse():
     p.add_argument("--recall-queries", type=int, default=10240,
                    help="queries the true recall is measured on (all 10 bench batches: standard error 0.0003)")
     p.add_argument("--index-cache", default=os.environ.get("HNSW_BENCH_CACHE", "/tmp/hnsw_bench_cache"))
-    return p.parse_args()
+    p.add_argument("--config", type=int, default=1, choices=[1, 2],
+                   help="BASELINE.json configs[i]: 1 = 1M x 100d fp32 L2, efSearch 64 (the metric); 2 = 10M x 768d fp32, "
+                        "unit-normalised rows (cosine order = L2 order), efSearch 128")
+    p.add_argument("--no-extras", action="store_true",
+                   help="skip the PCIe-inclusive rate and the recipe-B efSearch sweep (profiling passes)")
+    a = p.parse_args()
+    if a.config == 2:  # configs[2]; explicit flags still win
+        argv = " ".join(sys.argv[1:])
+        if "--n-points" not in argv:
+            a.n_points = 10_000_000
+        if "--dim" not in argv:
+            a.dim = 768
+        if "--ef" not in argv:
+            a.ef = "128"
+        if "--recall-queries" not in argv:
+            a.recall_queries = 2048
+        if "--steps" not in argv:
+            a.steps = 50
+        a.no_secondary = True
+        a.unit_rows = True
+    else:
+        a.unit_rows = False
+    return a
+
+
+def cpu_share():
+    """(threads to use, hardware concurrency, cgroup quota or None): the host cores this process may really
+    use -- min(hardware concurrency, CPU affinity, cgroup quota)"""
+    hw = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = hw
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(hw, aff, quota or hw)), hw, quota
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start the N ranks here, before this process touches a GPU (a
+    process that initialised HIP must not exec or fork workers), and hand on the child's line and code."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()  # counts devices without initialising them
+    if have < args.gpus:
+        sys.exit("bench.py --gpus %d: this node shows %d GPU(s)" % (args.gpus, have))
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("starting %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    sys.exit(subprocess.call(cmd))
 
 
 class Ctx:
     pass
+
+
+def make_rows(a, seed, first, n, threads, recipe=None):
+    """synthetic GloVe-shaped rows; configs[2]: unit-normalised, so that the
+    cosine order the config names is the L2 order the reference's metric gives"""
+    import hnsw_rs_amd as H
+    rows = H.synth_rows(a.recipe if recipe is None else recipe, seed, first, n, a.dim, threads)
+    if a.unit_rows:
+        rows /= np.linalg.norm(rows, axis=1, keepdims=True).astype(np.float32)
+    return rows
 
 
 def get_index(c, kind_name):
@@ -84,7 +165,7 @@ def get_index(c, kind_name):
     import hnsw_rs_amd as H
     a = c.args
     kind = H.VEC_QUANT8 if kind_name == "quant8" else H.VEC_F32
-    tag = "n%d_d%d_m%d_efc%d_%s_r%d" % (a.n_points, a.dim, a.m, a.ef_cons, kind_name, a.recipe)
+    tag = "n%d_d%d_m%d_efc%d_%s_r%d%s" % (a.n_points, a.dim, a.m, a.ef_cons, kind_name, a.recipe, "_unit" if a.unit_rows else "")
     cache_dir = os.path.join(a.index_cache, tag)
     index = None
     t0 = time.time()
@@ -97,14 +178,24 @@ def get_index(c, kind_name):
                 log("cache unusable (%s); rebuilding" % e)
                 shutil.rmtree(cache_dir, ignore_errors=True)
         if index is None:
-            store = H.synth_rows(a.recipe, 0x5EED0001, 0, a.n_points, a.dim, min(32, c.ncpu))
             t1 = time.time()
             index = H.HNSW.new(a.m, a.ef_cons, a.dim, kind)
-            if a.cpu_build:
-                index.insert_bulk(store, c.build_threads, False)
-            else:
-                index.set_device(c.local_rank)
-                index.insert_bulk_device(store, c.build_threads, False)
+            index.set_device(c.local_rank)
+            # rows are generated and handed over in slabs (HNSW::insert_bulk may be called repeatedly,
+            # template.rs:493-504): the host never holds more than one slab beside the index itself
+            slab = a.n_points
+            try:
+                avail = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1]) * 1024
+                if avail < 3 * 4 * a.dim * a.n_points:
+                    slab = max(1, min(a.n_points, (4 << 30) // (4 * a.dim)))
+            except (OSError, StopIteration, ValueError):
+                pass
+            for first in range(0, a.n_points, slab):
+                store = make_rows(a, 0x5EED0001, first, min(slab, a.n_points - first), min(32, c.ncpu))
+                if a.cpu_build:
+                    index.insert_bulk(store, c.build_threads, False)
+                else:
+                    index.insert_bulk_device(store, c.build_threads, False)
             log("built the %s index (%s, %d host threads) in %.1fs, %d layers" % (
                 kind_name, "host build" if a.cpu_build else "on-device build", c.build_threads,
                 time.time() - t1, index.nb_layers()))
@@ -198,19 +289,28 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
     bq = st[:, 0] * row_bytes + st[:, 1] * 4 + st[:, 2] * 4 + 4 * d + 8 * n
     bytes_per_launch = float(bq.mean() * B)
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM traffic comes from separate rocprofv3 PMC passes (scripts/profile.sh) and is only quoted while
+    # the kernels it was measured on are the ones running now (hash of the kernel sources)
+    traffic, traffic_from = None, None
     tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tfile):
         try:
-            for tj in json.load(open(tfile)).get("entries", []):
+            tdoc = json.load(open(tfile))
+            for tj in tdoc.get("entries", []):
                 if tj.get("workload") == tag and tj.get("ef") == ef and tj.get("batch") == B:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                    if tdoc.get("kernel_sources_sha16") == kernel_sources_sha16():
+                        traffic = tj.get("hbm_bytes_per_launch")
+                        traffic_from = {"commit": tdoc.get("commit"), "efSearch": ef, "profile": tdoc.get("profile")}
+                    else:
+                        traffic_from = {"stale": "kernels changed since commit %s; rerun scripts/profile.sh" % tdoc.get("commit")}
         except (OSError, ValueError, AttributeError):
             pass
     out["roofline"] = {
         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-        "kernel": "hx_search_kernel", "kernel_ms": round(kern_ms, 5),
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_measured_at": traffic_from,
+        "kernel": ("hx_lean_f32_kernel" if kind == H.VEC_F32 and d == 100 and ef <= 128 and
+                   os.environ.get("HNSW_MI355X_LEAN") != "0" else "hx_search_kernel"),
+        "kernel_ms": round(kern_ms, 5),
         "algorithmic_bytes_per_launch": round(bytes_per_launch),
         "per_query": {"n_dist": round(float(st[:, 0].mean()), 2), "n_exp": round(float(st[:, 1].mean()), 2),
                       "sum_deg": round(float(st[:, 2].mean()), 2), "bytes": round(float(bq.mean()), 1),
@@ -258,7 +358,7 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
         from oracle import oracle_py as O
         t2 = time.time()
         orc = O.OracleHNSW(m, a.ef_cons, d, kind)
-        store = H.synth_rows(a.recipe, 0x5EED0001, 0, N, d, min(32, c.ncpu))
+        store = make_rows(a, 0x5EED0001, 0, N, min(32, c.ncpu))
         lv = np.zeros(N, dtype=np.uint8)
         for l in range(1, index.nb_layers()):
             lv[index.get_layer(l).iter_nodes()] = l
@@ -268,7 +368,10 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
             orc.import_layer(l, *index.get_layer(l).csr())
         orc.set_ep(int(index.params.ep))
         log("oracle holds the same %s index (%.1fs)" % (kind_name, time.time() - t2))
-        T = a.cpu_threads or max(1, min(16, c.ncpu))
+        # T = std::thread::hardware_concurrency() as far as this process may use it: the cgroup quota and
+        # the CPU affinity bound it (a GPU box hands 16 of its 256 hardware threads to one GPU's job)
+        T_share, hw, quota = cpu_share()
+        T = a.cpu_threads or T_share
         qcpu = c.queries.reshape(nqb, B * c.world, d)[:, :B].reshape(-1, d)
         t3 = time.time()
         reps = 0
@@ -287,6 +390,7 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
             "sample": "%d queries (the %d bench batches) x %d passes on %d threads = %.1f s wall; "
                       "1 thread: %.0f queries/s on 2048 queries" % (qcpu.shape[0], nqb, reps, T, cpu_s, 2048 / one_s),
             "single_thread_value": round(2048 / one_s, 1),
+            "hardware_concurrency": hw, "cpu_quota": quota,
             "host_cpu": next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo")
                               if l.startswith("model name")), "unknown"),
         }
@@ -298,8 +402,77 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
     return out
 
 
+def extras(c, index, kind_name, ef, local_search):
+    """SURVEY 8(d) figures beside the metric (rank 0, one GPU): the PCIe-inclusive rate of the host-pointer
+    entry, and the efSearch sweep on the hard isotropic recipe B"""
+    import hnsw_rs_amd as H
+    a, torch = c.args, c.torch
+    n, B, nqb = a.topn, a.batch, a.query_batches
+    out = {}
+    # ---- hnsw_search_batch: pageable host buffers in, host buffers out, one H2D + one D2H per call ----
+    try:
+        qh = [np.ascontiguousarray(c.queries.reshape(nqb, -1, a.dim)[b][:B]) for b in range(nqb)]
+        for b in range(min(3, nqb)):
+            index.search_batch(qh[b], n, ef)
+        steps = 40 if a.config == 1 else 10
+        t0 = time.perf_counter()
+        for i in range(steps):
+            index.search_batch(qh[i % nqb], n, ef)
+        dt = time.perf_counter() - t0
+        out["pcie_inclusive"] = {"queries_per_s": round(steps * B / dt, 1), "ms_per_step": round(dt / steps * 1e3, 5),
+                                 "efSearch": ef, "entry": "hnsw_search_batch (host pointers; H2D of the queries, D2H of ids / "
+                                 "distances / counts / statistics, status check and overflow retry included)",
+                                 "note": "never reported as `value`"}
+    except Exception as e:
+        log("pcie-inclusive measurement skipped: %s" % e)
+    # ---- recipe B (isotropic clusters, SURVEY 8d): qps at the first efSearch that reaches the recall ----
+    if a.config == 1 and a.recipe == 0:
+        try:
+            from hnsw_rs_amd.distributed import make_device_search
+            t0 = time.time()
+            kind = H.VEC_QUANT8 if kind_name == "quant8" else H.VEC_F32
+            idxb = H.HNSW.new(a.m, a.ef_cons, a.dim, kind)
+            idxb.set_device(c.local_rank)
+            idxb.insert_bulk_device(make_rows(a, 0x5EED0001, 0, a.n_points, min(32, c.ncpu), recipe=1), c.build_threads, False)
+            idxb.upload()
+            qb = make_rows(a, 0x5EED0002, 0, 2 * B, min(16, c.ncpu), recipe=1)
+            dqb = torch.from_numpy(qb).to(c.dev)
+            truth, _ = idxb.brute_force(qb[:B], n)
+            sweep = []
+            for e in (64, 128, 256, 512):
+                ls = make_device_search(idxb, n, e, B, c.dev)
+                got, _ = ls(dqb[:B].contiguous())
+                ls.check()
+                got = got.cpu().numpy().view(np.uint32)
+                rec = sum(len(set(x.tolist()) & set(y.tolist())) for x, y in zip(got, truth)) / float(B * n)
+                for _ in range(3):
+                    ls(dqb[B:].contiguous())
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for i in range(10):
+                    ls(dqb[(i % 2) * B:(i % 2 + 1) * B].contiguous())
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 10
+                sweep.append({"efSearch": e, "recall_at_%d" % n: round(rec, 4), "queries_per_s": round(B / ms * 1e3, 1),
+                              "ms_per_step": round(ms, 5)})
+            out["recipe_B_ef_sweep"] = {"data": "recipe B: 4096 isotropic clusters, the hard case of SURVEY 8(d); M=%d "
+                                        "ef_construction=%d" % (a.m, a.ef_cons), "vec_kind": kind_name,
+                                        "recall_queries": B, "sweep": sweep,
+                                        "note": "this graph does not reach recall 0.99 at M=16 / ef_construction=32 on "
+                                                "this data whoever builds it (DESIGN.md section 10)"}
+            log("recipe B sweep done in %.1fs" % (time.time() - t0))
+            del idxb
+        except Exception as e:
+            log("recipe-B sweep skipped: %s" % e)
+    return out
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # does not return
     # Exactly ONE line on stdout: libraries (RCCL prints a version banner) write to fd 1 too, so the
     # real stdout is set aside for the JSON line and fd 1 points to stderr for everything else.
     sys.stdout.flush()
@@ -318,7 +491,7 @@ def main():
     c.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world, rank = c.world, c.rank
     if world != args.gpus:
-        log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+        sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     torch.cuda.set_device(c.local_rank)
@@ -332,12 +505,15 @@ def main():
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ["MASTER_PORT"] = os.environ.get("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus and not force_dist:
+            sys.exit("RCCL communicator has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
+    n_gpus = dist.get_world_size() if use_dist else 1
 
     N, d, m, n, B = args.n_points, args.dim, args.m, args.topn, args.batch
     c.ncpu = os.cpu_count() or 8
     c.build_threads = args.build_threads or max(1, min(32, c.ncpu // max(1, world)))
     nqb = args.query_batches
-    c.queries = H.synth_rows(args.recipe, 0x5EED0002, 0, nqb * B * world, d, min(16, c.ncpu))
+    c.queries = make_rows(args, 0x5EED0002, 0, nqb * B * world, min(16, c.ncpu))
     c.dQ = torch.from_numpy(c.queries).to(dev).view(nqb, B * world, d) if rank == 0 else None
 
     # ---- the timed kind ---------------------------------------------------------------------------
@@ -396,17 +572,23 @@ def main():
                      "quant8": "8-bit codes dequantised to f32 (reference VecType = QuantVec, as shipped)"}
         out = {
             "metric": "queries/sec at recall@10>=0.99, 1M x 100d L2",
-            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": round(qps, 1), "unit": "queries/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
             "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d x %dd fp32 L2, M=%d efSearch=%d, batch=%d queries per GPU; "
+            "config": {"workload": "configs[%d]: %d x %dd fp32 L2%s, M=%d efSearch=%d, batch=%d queries per GPU; "
                                    "index rows: %s; synthetic GloVe-shaped recipe %s" % (
-                                       N, d, m, ef, B, kind_note[args.kind], "AB"[args.recipe]),
+                                       args.config, N, d,
+                                       " on unit-normalised rows (cosine order = L2 order; the reference has no cosine metric)"
+                                       if args.unit_rows else "", m, ef, B, kind_note[args.kind], "AB"[args.recipe]),
                        "n_points": N, "dim": d, "M": m, "ef_construction": args.ef_cons, "efSearch": ef,
                        "n": n, "batch_per_gpu": B, "vec_kind": args.kind,
                        "parallelism": "replicated index, query batch sharded over %d GPU(s)" % world},
         }
         out.update(result)
+        if args.config == 2:
+            out["metric"] = "queries/sec, %d x %dd fp32, unit rows, efSearch %d (BASELINE configs[2]; recall@10 reported)" % (N, d, ef)
+        if world == 1 and not args.no_extras:
+            out.update(extras(c, index, args.kind, ef, local_search))
         # ---- the other vector kind, same run (single GPU only) ---------------------------------------
         if world == 1 and not args.no_secondary:
             other = "quant8" if args.kind == "f32" else "f32"

@@ -10,6 +10,10 @@ import sys
 out = sys.argv[1]
 
 
+def is_search(name):
+    return "hx_search_kernel" in name or "hx_lean_f32_kernel" in name
+
+
 def find(pattern):
     r = glob.glob(os.path.join(out, pattern), recursive=True)
     return r[0] if r else None
@@ -39,7 +43,7 @@ for kind in ("f32", "quant8"):
                 print(", ".join(row))
     tr = find("trace_%s/**/*kernel_trace.csv" % kind)
     if tr:
-        rows = [r for r in csv.DictReader(open(tr)) if "hx_search_kernel" in r.get("Kernel_Name", "")]
+        rows = [r for r in csv.DictReader(open(tr)) if is_search(r.get("Kernel_Name", ""))]
         # the timed efSearch is the kernel instantiation with the most dispatches (warm-up + timed + the
         # counter pass); the recall ladder and the efSearch-64 side measurement use other list widths
         names = {}
@@ -62,7 +66,7 @@ for kind in ("f32", "quant8"):
         if not f:
             continue
         prow = [r for r in csv.DictReader(open(f))
-                if "hx_search_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == cname]
+                if is_search(r.get("Kernel_Name", "")) and r.get("Counter_Name") == cname]
         pn = {}
         for r in prow:
             pn[r["Kernel_Name"]] = pn.get(r["Kernel_Name"], 0) + 1
@@ -84,7 +88,18 @@ for kind in ("f32", "quant8"):
                                                                  a["ef_construction"], kind),
                         "ef": a["efSearch"], "batch": a["batch_per_gpu"], "fetch_size_kb_raw": fetch_kb,
                         "write_size_kb": write_kb, "hbm_bytes_per_launch": hbm})
-json.dump({"entries": entries,
+import hashlib
+import subprocess
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+hh = hashlib.sha256()
+for f in ("search_kernels.hip", "search_lean.hip", "device_index.h"):
+    hh.update(open(os.path.join(root, "hnsw_rs_amd", "csrc", f), "rb").read())
+try:
+    commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    commit = os.environ.get("HNSW_PROFILE_COMMIT", "unknown")
+json.dump({"entries": entries, "kernel_sources_sha16": hh.hexdigest()[:16], "commit": commit,
+           "profile": os.path.basename(os.path.normpath(out)),
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (scripts/profile.sh); "
                    "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB: gfx950 tallies the 128-B requests "
                    "of 16-B/lane loads (LDS-DMA included) at 64 B (MI355X_MICROARCH.md, HBM)"},
