@@ -11,7 +11,6 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="--steps 100 --warmup 10"
-export HNSW_PROFILE_COMMIT=$(git -C $REPO rev-parse --short HEAD 2>/dev/null || echo unknown)
 cd $REPO
 python bench.py $ARGS 2> $OUT/bench.err | tee $OUT/bench.json || exit 1
 for KIND in f32 quant8; do

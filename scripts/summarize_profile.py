@@ -95,9 +95,11 @@ hh = hashlib.sha256()
 for f in ("search_kernels.hip", "search_lean.hip", "device_index.h"):
     hh.update(open(os.path.join(root, "hnsw_rs_amd", "csrc", f), "rb").read())
 try:
-    commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
-except Exception:
-    commit = os.environ.get("HNSW_PROFILE_COMMIT", "unknown")
+    commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True,
+                                     stderr=subprocess.DEVNULL).strip()
+except Exception:  # the GPU box gets a snapshot without .git: the caller leaves the commit in a file
+    cf = os.path.join(root, ".commit_for_profile")
+    commit = open(cf).read().strip() if os.path.exists(cf) else "unknown"
 json.dump({"entries": entries, "kernel_sources_sha16": hh.hexdigest()[:16], "commit": commit,
            "profile": os.path.basename(os.path.normpath(out)),
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (scripts/profile.sh); "
