@@ -308,8 +308,9 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
     out["roofline"] = {
         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_measured_at": traffic_from,
-        "kernel": ("hx_lean_f32_kernel" if kind == H.VEC_F32 and d == 100 and ef <= 128 and
-                   os.environ.get("HNSW_MI355X_LEAN") != "0" else "hx_search_kernel"),
+        "kernel": (("hx_lean_f32_kernel" if kind == H.VEC_F32 else "hx_lean_q8_kernel")
+                   if d == 100 and ef <= 128 and os.environ.get("HNSW_MI355X_LEAN") != "0" and
+                   (kind == H.VEC_F32 or os.environ.get("HNSW_MI355X_LEAN_Q8") != "0") else "hx_search_kernel"),
         "kernel_ms": round(kern_ms, 5),
         "algorithmic_bytes_per_launch": round(bytes_per_launch),
         "per_query": {"n_dist": round(float(st[:, 0].mean()), 2), "n_exp": round(float(st[:, 1].mean()), 2),

@@ -171,6 +171,11 @@ int DeviceIndex::upload(const HostIndex &idx, int dev) {
         if (const char *e = getenv("HNSW_MI355X_INLINE_ROWS")) want = atoi(e);
         const uint32_t used = 8 + v.nch4 + v.rem;
         const bool room = idx.kind == HNSW_VEC_QUANT8 && v.S0 == 32 && v.half_bytes >= used + 4;
+        // d = 100 is served by the lean compact-layout kernel (search_lean.hip), faster at every launch size
+        // than the inline-rows loop: the 4-GB copy is only built there when asked for explicitly
+        if (want < 0 && idx.dim == 100 && !(getenv("HNSW_MI355X_LEAN_Q8") && atoi(getenv("HNSW_MI355X_LEAN_Q8")) == 0) &&
+            !(getenv("HNSW_MI355X_LEAN") && atoi(getenv("HNSW_MI355X_LEAN")) == 0))
+            want = 0;
         const uint64_t need = (uint64_t)N * v.S0 * v.row_stride;
         if (room && (want == 1 || (want < 0 && need <= fat_budget_bytes))) {
             v.fat_stride = (uint64_t)v.S0 * v.row_stride;

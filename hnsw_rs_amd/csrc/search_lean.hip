@@ -32,18 +32,17 @@
 #include <cstdlib>
 
 #include "device_index.h"
+#include "search_common.h"
 
 namespace hx {
 namespace {
 
-typedef unsigned long long u64;
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr u64 LK_INVALID = ~0ull;
 constexpr u64 LK_MASK = 0x7FFFFFFFFFFFFFFFull;
 constexpr u64 LK_EXPANDED = 1ull << 63;
 
 struct LeanArgs {
-    const float *rows;           // N x DS floats
+    const float *rows;           // F32: N x DS floats; QUANT8: the packed half rows (device_index.h)
     const uint32_t *adj0;        // N x S0
     const uint32_t *adj_up;      // rows of S1
     const uint32_t *upper_base;  // N
@@ -729,6 +728,345 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
     }
 }
 
+// =============================================================================================
+// QuantVec rows (the reference's shipped VecType, points/src/point.rs:4), d = 100, compact layout: a
+// row is one 128-byte line, a lane PAIR evaluates a neighbour (lane h streams half h: four of
+// distance_unrolled's eight running sums, quant.rs:14-37).  One adjacency row (32 slots) fills the wave,
+// so a pass expands one candidate; the adjacency row of the runner-up is requested at the pick and is
+// there when the runner-up is next (three times out of four).  Same list, visited set and upper-layer
+// walk as the f32 kernel above.  Against the inline-rows layout of hx_search_kernel this reads 128 B per
+// evaluated neighbour instead of a whole 4-KiB block per expansion (measured traffic / algorithmic bytes
+// 2.1 there) and needs no 4-GB copy of the rows.
+// =============================================================================================
+template <int R>
+__global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
+    constexpr int DS = 100, P = 4, NQ = 4 * (DS / 8) + DS % 8;  // 52 query values per half (half 1 uses 48)
+    constexpr uint32_t HALF = 64, ROW = 128, NCH4 = 4 * (DS / 8), REM = DS % 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int h = lane & 1;
+    const uint32_t cslot = (uint32_t)lane >> 1;
+    const uint32_t q = a.qsel ? a.qsel[blockIdx.x] : blockIdx.x;
+    const uint32_t hslots = 1u << a.slots_log2;
+    u64 *perm = reinterpret_cast<u64 *>(smem + 4ull * hslots);
+    float *yq = reinterpret_cast<float *>(perm + 64 * R);
+    Visited vis;
+    vis.tab = reinterpret_cast<uint32_t *>(smem);
+    const uint8_t *rows8 = reinterpret_cast<const uint8_t *>(a.rows);
+
+    uint32_t n_dist = 0, n_exp = 0, sum_deg = 0, n_vis = 0;
+    int32_t status = HNSW_OK;
+
+    // ---- the query goes through the same quantiser as a stored vector (Point::new -> QuantVec::new,
+    // template.rs:313, quant.rs:41-66) and is kept dequantised, in this lane's half order, in registers ----
+    QRegs<NQ> qreg;
+    {
+        DevView dv{};
+        dv.dim = DS;
+        dv.half_bytes = HALF;
+        dv.nch4 = NCH4;
+        dv.rem = REM;
+        if (!stage_query<HNSW_VEC_QUANT8>(dv, a.Q + (size_t)q * DS, yq, lane)) status = HNSW_ERR_NAN_INPUT;
+#pragma unroll
+        for (int e = 0; e < NQ; e++) qreg.v[e] = yq[h * (HALF - 8) + e];
+    }
+    // distance of the neighbour of this lane pair; the result is on the even lane
+    auto eval = [&](uint32_t id, bool want) __attribute__((always_inline)) -> float {
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (want) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(rows8 + (size_t)id * ROW + (size_t)h * HALF);
+            uint4 w[P];
+#pragma unroll
+            for (int p = 0; p < P; p++) w[p] = src[p];
+            __builtin_amdgcn_sched_barrier(0);
+            quant_half_sums<P, DS>(w, qreg, h, NCH4, REM, acc);
+        }
+        // acc.iter().sum(): ((((((a0+a1)+a2)+a3)+a4)+a5)+a6)+a7 with a4..a7 on the odd lane
+        const float b0 = pair_swap(acc[0]), b1 = pair_swap(acc[1]), b2 = pair_swap(acc[2]), b3 = pair_swap(acc[3]);
+        float s = 0.0f;
+        s += acc[0];
+        s += acc[1];
+        s += acc[2];
+        s += acc[3];
+        s += b0;
+        s += b1;
+        s += b2;
+        s += b3;
+        return __builtin_sqrtf(s);
+    };
+    // exact insert of the even lanes' ids; both lanes of a pair learn the outcome
+    auto pair_insert = [&](uint32_t id, bool ins) __attribute__((always_inline)) -> bool {
+        const bool f = vis.insert(id, ins && h == 0);
+        return (pair_swap_i(f ? 1 : 0) | (f ? 1 : 0)) != 0;
+    };
+
+    // ---- entry point (template.rs:316-319) ----
+    u64 best = LK_INVALID;
+    uint32_t cur = a.ep;
+    if (status == HNSW_OK) {
+        if (cur >= a.n_points) {
+            status = HNSW_ERR_ARG;
+        } else {
+            const float d0 = eval(cur, lane < 2);
+            const uint32_t bits = rdlane(__builtin_bit_cast(uint32_t, d0), 0);
+            n_dist = 1;
+            if (__builtin_bit_cast(float, bits) != __builtin_bit_cast(float, bits))
+                status = HNSW_ERR_NAN_INPUT;
+            else
+                best = ((u64)bits << 32) | cur;
+        }
+    }
+
+    // ---- upper layers, ef = 1: the greedy walk of the f32 kernel, a lane pair per neighbour ----
+    const uint32_t up_slots = max(hslots >> 2, 64u);
+    uint32_t ub_cur = HX_EMPTY_SLOT;
+    bool have_ub = false;
+    for (int layer = (int)a.nb_layers - 1; layer >= 1 && status == HNSW_OK; layer--) {
+        vis.bshift = 32 - (__ffs((int)up_slots) - 1 - 2);
+        vis.bmask = (up_slots >> 2) - 1;
+        const uint32_t vis_limit = up_slots - (up_slots >> 2);
+        vis.clear(up_slots, lane);
+        vis.insert(cur, lane == 0);
+        n_vis = 1;
+        if (!have_ub) {
+            ub_cur = uni(a.upper_base[cur]);
+            have_ub = true;
+        }
+        while (status == HNSW_OK) {
+            if (ub_cur == HX_EMPTY_SLOT) {  // Graph::neighbors_vec -> NodeNotInGraph (searcher.rs:45-50)
+                status = HNSW_ERR_NODE_NOT_IN_GRAPH;
+                break;
+            }
+            n_exp++;
+            bool improved = false;
+            uint32_t new_cur = cur, new_ub = ub_cur;
+            const uint32_t *row = a.adj_up + ((size_t)ub_cur + (uint32_t)layer - 1) * a.S1;
+            uint32_t ovf_lo = 0, ovf_hi = 0;
+            for (uint32_t c0 = 0; c0 < a.S1 || ovf_lo < ovf_hi; c0 += 32) {
+                uint32_t nb = HX_EMPTY_SLOT;
+                if (c0 < a.S1) {
+                    if (c0 + cslot < a.S1) nb = row[c0 + cslot];
+                    const u64 pm = __ballot((int32_t)nb < -1);
+                    if (pm) {
+                        const uint32_t o = rdlane(nb, (uint32_t)__ffsll((long long)pm) - 1) & ~HX_OVF_FLAG;
+                        ovf_lo = uni(a.ovf_off[o]);
+                        ovf_hi = uni(a.ovf_off[o + 1]);
+                    }
+                } else {
+                    if (ovf_lo + cslot < ovf_hi) nb = a.ovf_nbrs[ovf_lo + cslot];
+                    ovf_lo += 32;
+                }
+                const bool valid = (int32_t)nb >= 0;
+                const uint32_t cnt = (uint32_t)__popcll(__ballot(valid && h == 0));
+                sum_deg += cnt;
+                if (cnt == 0) continue;
+                if (n_vis + cnt > vis_limit) {
+                    status = HNSW_ERR_OVERFLOW;
+                    break;
+                }
+                const bool fresh = pair_insert(nb, valid);
+                const u64 fm = __ballot(fresh && h == 0);
+                const uint32_t nf = (uint32_t)__popcll(fm);
+                n_vis += nf;
+                n_dist += nf;
+                if (fm == 0) continue;
+                uint32_t ubn = HX_EMPTY_SLOT;
+                if (fresh && h == 0) ubn = a.upper_base[nb];  // in flight together with the vector row
+                const float dist = eval(nb, fresh);
+                const bool mine = fresh && h == 0;
+                if (__ballot(mine && dist != dist)) {
+                    status = HNSW_ERR_NAN_INPUT;  // Dist::cmp would panic (dist.rs:32)
+                    break;
+                }
+                const uint32_t db = mine ? __builtin_bit_cast(uint32_t, dist) : 0xFFFFFFFFu;
+                const uint32_t mn = wave_min_u32(db);
+                u64 tie = __ballot(mine && db == mn);
+                uint32_t j = (uint32_t)__ffsll((long long)tie) - 1;
+                uint32_t bid = rdlane(nb, j);
+                tie &= tie - 1;
+                while (tie) {  // equal distances: the smaller id wins (dist.rs:30-38)
+                    const uint32_t j2 = (uint32_t)__ffsll((long long)tie) - 1;
+                    tie &= tie - 1;
+                    const uint32_t id2 = rdlane(nb, j2);
+                    if (id2 < bid) {
+                        bid = id2;
+                        j = j2;
+                    }
+                }
+                const u64 k = ((u64)mn << 32) | bid;
+                if (k < best) {
+                    best = k;
+                    new_cur = bid;
+                    new_ub = rdlane(ubn, j);
+                    improved = true;
+                }
+            }
+            if (!improved || status != HNSW_OK) break;
+            cur = new_cur;
+            ub_cur = new_ub;
+        }
+    }
+
+    // ---- layer 0 with ef (template.rs:326) ----
+    const uint32_t ef = max(1u, a.ef);
+    Lst<R> lst;
+    lst.init();
+    if (status == HNSW_OK) {
+        vis.bshift = 32 - (a.slots_log2 - 2);
+        vis.bmask = (hslots >> 2) - 1;
+        const uint32_t vis_limit = hslots - (hslots >> 2);  // 75 % load at most
+        vis.clear(hslots, lane);
+        vis.insert(cur, lane == 0);
+        n_vis = 1;
+        if (lane == 0) lst.L[0] = best;
+        lst.n_cur = 1;
+        lst.refresh_last(ef);
+        const uint32_t S0 = a.S0;
+        uint32_t pre_nb = HX_EMPTY_SLOT, pre_c = HX_EMPTY_SLOT;  // adjacency row requested ahead
+
+        // One candidate per pass.  (Evaluating the runner-up as well -- its rows fetched together with
+        // c's, its chain run when it is committed -- was built, parity-tested and measured slower:
+        // 0.196 against 0.180 ms per batch at efSearch 68.)
+        while (true) {
+            u64 U[R];
+            lst.unexp_masks(U);
+            const int cpos = Lst<R>::take_first(U);
+            if (cpos < 0) break;  // candidates exhausted / only worse ones left (searcher.rs:35,41-44)
+            const int ppos = Lst<R>::take_first(U);
+            const uint32_t cid = lst.id_at((uint32_t)cpos);
+            lst.mark((uint32_t)cpos, lane);
+            n_exp++;
+            uint32_t nb;
+            if (pre_c == cid) {
+                nb = pre_nb;
+            } else {
+                nb = HX_EMPTY_SLOT;
+                if (cslot < S0) nb = a.adj0[(size_t)cid * S0 + cslot];
+            }
+            // the runner-up is the next candidate three times out of four: its adjacency row is requested
+            // now and lands while this pass filters, evaluates and merges
+            pre_c = HX_EMPTY_SLOT;
+            if (ppos >= 0) {
+                pre_c = lst.id_at((uint32_t)ppos);
+                pre_nb = HX_EMPTY_SLOT;
+                if (cslot < S0) pre_nb = a.adj0[(size_t)pre_c * S0 + cslot];
+            }
+            const u64 pm = __ballot((int32_t)nb < -1);  // 0x80000000 | overflow row (degree > S0, rare)
+            const bool valid = (int32_t)nb >= 0;
+            // ---- visited: the pair looks at the id's home bucket, the even lane claims a slot ----
+            const uint32_t vb = vis.home(nb);
+            const uint32_t vt0 = vis.look(nb, vb);
+            const uint32_t ct = (valid && h == 0) ? vt0 : 4u;
+            const uint32_t old = vis.claim(nb, vb, ct);
+            bool fresh0 = old == HX_EMPTY_SLOT;
+            const bool pend = (ct != 4u) & !fresh0;
+            if (__ballot(pend)) fresh0 = vis.finish(nb, vb, ct, pend, fresh0);
+            const bool fresh = (pair_swap_i(fresh0 ? 1 : 0) | (fresh0 ? 1 : 0)) != 0;
+            const u64 vmask = __ballot(valid && h == 0), fmask = __ballot(fresh0);
+            const uint32_t nf = (uint32_t)__popcll(fmask);
+            sum_deg += (uint32_t)__popcll(vmask);
+            n_vis += nf;
+            n_dist += nf;
+            if (n_vis > vis_limit) {  // the table holds at most vis_limit + 32 ids
+                status = HNSW_ERR_OVERFLOW;
+                break;
+            }
+            u64 key = LK_INVALID;
+            if (fmask) {
+                const float dist = eval(nb, fresh);
+                const bool mine = fresh0;
+                if (__ballot(mine && dist != dist)) {
+                    status = HNSW_ERR_NAN_INPUT;  // Dist::cmp would panic (dist.rs:32)
+                    break;
+                }
+                if (mine) key = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | nb;
+            }
+            lst.merge(key, ef, perm, lane);
+            if (pm) {  // degree > S0: the rest of the row
+                const uint32_t c_ovf = rdlane(nb, (uint32_t)__ffsll((long long)pm) - 1) & ~HX_OVF_FLAG;
+                const uint32_t lo = uni(a.ovf_off[c_ovf]), hi = uni(a.ovf_off[c_ovf + 1]);
+                for (uint32_t base = lo; base < hi && status == HNSW_OK; base += 32) {
+                    const uint32_t i = base + cslot;
+                    const bool ov = i < hi;
+                    const uint32_t onb = ov ? a.ovf_nbrs[i] : HX_EMPTY_SLOT;
+                    const uint32_t ocnt = (uint32_t)__popcll(__ballot(ov && h == 0));
+                    sum_deg += ocnt;
+                    if (n_vis + ocnt > vis_limit) {
+                        status = HNSW_ERR_OVERFLOW;
+                        break;
+                    }
+                    const bool ofresh = pair_insert(onb, ov);
+                    const uint32_t onf = (uint32_t)__popcll(__ballot(ofresh && h == 0));
+                    n_vis += onf;
+                    n_dist += onf;
+                    if (onf == 0) continue;
+                    const float odist = eval(onb, ofresh);
+                    const bool omine = ofresh && h == 0;
+                    if (__ballot(omine && odist != odist)) {
+                        status = HNSW_ERR_NAN_INPUT;
+                        break;
+                    }
+                    lst.merge(omine ? (((u64)__builtin_bit_cast(uint32_t, odist) << 32) | onb) : LK_INVALID, ef, perm,
+                              lane);
+                }
+                if (status != HNSW_OK) break;
+            }
+        }
+    }
+
+    // ---- get_top_selected(n) (results.rs:59-61): the first n entries of the ascending list ----
+    const uint32_t count = status == HNSW_OK ? min(a.n, lst.n_cur) : 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t idx = (uint32_t)(R * lane + r);
+        if (idx < a.n) {
+            const bool have = idx < count;
+            a.out_ids[(size_t)q * a.n + idx] = have ? (uint32_t)lst.L[r] : HX_EMPTY_SLOT;
+            if (a.out_dists)
+                a.out_dists[(size_t)q * a.n + idx] =
+                    have ? __builtin_bit_cast(float, (uint32_t)((lst.L[r] & LK_MASK) >> 32)) : __builtin_inff();
+        }
+    }
+    for (uint32_t idx = 64u * R + lane; idx < a.n; idx += 64) {  // n beyond the list capacity: padding
+        a.out_ids[(size_t)q * a.n + idx] = HX_EMPTY_SLOT;
+        if (a.out_dists) a.out_dists[(size_t)q * a.n + idx] = __builtin_inff();
+    }
+    if (lane == 0) {
+        if (a.out_counts) a.out_counts[q] = count;
+        hnsw_query_stats st;
+        st.n_dist = n_dist;
+        st.n_exp = n_exp;
+        st.sum_deg = sum_deg;
+        st.status = status;
+        a.out_stats[q] = st;
+    }
+}
+
+template <int R>
+int launch_lean_q8(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
+    const size_t lds = (4ull << a.slots_log2) + 64ull * R * 8 + 2 * 56 * 4;
+    auto kern = hx_lean_q8_kernel<R>;
+    if (lds > 160 * 1024) {
+        set_error("search needs %zu bytes of LDS (> 160 KiB)", lds);
+        return HNSW_ERR_ARG;
+    }
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+            return HNSW_ERR_HIP;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64), lds, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("search kernel launch: %s", hipGetErrorString(e));
+        return HNSW_ERR_HIP;
+    }
+    return HNSW_OK;
+}
+
 template <int DS, int R>
 int launch_lean_one(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
     const size_t lds = (4ull << a.slots_log2) + 64ull * R * 8;
@@ -761,7 +1099,10 @@ int launch_lean_one(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
 bool lean_applicable(const DevView &v, const SearchArgs &a, uint32_t ef_max) {
     static const bool enabled = !(getenv("HNSW_MI355X_LEAN") && atoi(getenv("HNSW_MI355X_LEAN")) == 0);
     if (!enabled) return false;
-    if (v.kind != HNSW_VEC_F32 || v.dim != 100 || v.row_stride != 400) return false;
+    static const bool q8_enabled = !(getenv("HNSW_MI355X_LEAN_Q8") && atoi(getenv("HNSW_MI355X_LEAN_Q8")) == 0);
+    const bool f32_ok = v.kind == HNSW_VEC_F32 && v.dim == 100 && v.row_stride == 400;
+    const bool q8_ok = q8_enabled && v.kind == HNSW_VEC_QUANT8 && v.dim == 100 && v.row_stride == 128 && v.half_bytes == 64;
+    if (!f32_ok && !q8_ok) return false;
     if (a.entries != nullptr || a.layer_lo != 0 || a.layer_hi != (int32_t)v.nb_layers - 1) return false;
     if (a.layer_hi > 0 && a.ef_upper != 1) return false;
     if (v.S0 > 32 || v.S1 > 64 || ef_max > 128 || (a.flags & 1u)) return false;
@@ -791,6 +1132,10 @@ int launch_lean(const DevView &v, const SearchArgs &s, uint32_t nblocks, uint32_
     a.n = s.n;
     a.slots_log2 = slots_log2;
     a.dbg = s.dbg;
+    if (v.kind == HNSW_VEC_QUANT8) {
+        if (a.ef <= 64) return launch_lean_q8<1>(a, nblocks, stream);
+        return launch_lean_q8<2>(a, nblocks, stream);
+    }
     if (a.ef <= 64) return launch_lean_one<100, 1>(a, nblocks, stream);
     return launch_lean_one<100, 2>(a, nblocks, stream);
 }

@@ -11,7 +11,7 @@ out = sys.argv[1]
 
 
 def is_search(name):
-    return "hx_search_kernel" in name or "hx_lean_f32_kernel" in name
+    return "hx_search_kernel" in name or "hx_lean_f32_kernel" in name or "hx_lean_q8_kernel" in name
 
 
 def find(pattern):
