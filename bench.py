@@ -223,7 +223,19 @@ def choose_ef(c, index, kind_name):
     recall_by_ef = {}
     nr = min(a.recall_queries, c.queries.shape[0])
     qh = c.queries[:nr]
-    bf, _ = index.brute_force(qh, n)
+    # ground truth: the exact scan; for f32 rows the MFMA scan (screen + exact re-rank) after it has been
+    # checked against the exact scan on the first 256 queries of this very index
+    c.ground_truth = "exact scan (hx_brute_kernel)"
+    if kind_name == "f32" and a.dim % 4 == 0 and n <= 12:
+        bf, _ = index.brute_force_fast(qh, n)
+        chk, _ = index.brute_force(qh[:256], n)
+        if np.array_equal(chk, bf[:256]):
+            c.ground_truth = "MFMA scan + exact re-rank (hx_brute_mfma_kernel), equal to the exact scan on 256 queries"
+        else:
+            log("MFMA scan differs from the exact scan on this index; using the exact scan")
+            bf, _ = index.brute_force(qh, n)
+    else:
+        bf, _ = index.brute_force(qh, n)
 
     def recall_at(e):
         got, _, _, _ = index.search_batch(qh, n, e)
@@ -318,6 +330,7 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
                       "row_bytes": row_bytes},
     }
     out["recall_at_%d" % n] = recall_by_ef[ef]
+    out["ground_truth"] = getattr(c, "ground_truth", None)
     out["recall_by_ef"] = {str(k): v for k, v in sorted(recall_by_ef.items())}
     if ef != 64:  # the configured efSearch = 64 timed too when the metric's recall needed a larger ef
         from hnsw_rs_amd.distributed import make_device_search

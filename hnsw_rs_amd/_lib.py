@@ -77,6 +77,7 @@ SYMBOLS = {
     "hnsw_search_layer": (C.c_int, [vp, C.c_uint32, f32p, u32p, C.c_uint32, C.c_uint32, u32p, f32p, u32p,
                                     C.POINTER(QueryStats)]),
     "hnsw_brute_force": (C.c_int, [vp, f32p, C.c_uint64, C.c_uint32, u32p, f32p]),
+    "hnsw_brute_force_fast": (C.c_int, [vp, f32p, C.c_uint64, C.c_uint32, u32p, f32p]),
     "hnsw_len": (C.c_uint64, [vp]),
     "hnsw_distance": (C.c_int, [vp, C.c_uint32, C.c_uint32, f32p]),
     "hnsw_get_vector": (C.c_int, [vp, C.c_uint32, f32p]),

@@ -1197,6 +1197,103 @@ int hnsw_brute_force(hnsw_index *h, const float *Q, uint64_t nq, uint32_t k, uin
     return HNSW_OK;
 }
 
+// Ground truth on the matrix cores (brute_mfma.hip): MFMA scores screen every point, the k + 8 best per
+// query are re-evaluated in the reference's exact arithmetic and sorted by (dist, id).  Not bit-exact by
+// construction (the screen could in principle lose a true neighbour to rounding): hnsw_brute_force is the
+// exact scan; this one is for ground truth at sizes where the exact scan takes minutes.
+int hnsw_brute_force_fast(hnsw_index *h, const float *Q, uint64_t nq, uint32_t k, uint32_t *ids, float *dists) {
+    int rc = check_search_args(h, 1);
+    if (rc != HNSW_OK) return rc;
+    if (nq == 0) return HNSW_OK;
+    const uint32_t K2 = hx::brute_mfma_k2();
+    if (!Q || !ids || k == 0 || k + 8 > K2) {
+        set_error("the MFMA scan supports 1 <= k <= %u", K2 - 8);
+        return HNSW_ERR_ARG;
+    }
+    rc = ensure_uploaded(h);
+    if (rc != HNSW_OK) return rc;
+    const hx::DevView &v = h->dev.view;
+    if (v.kind != HNSW_VEC_F32 || (v.dim & 3u)) {
+        set_error("the MFMA scan serves f32 rows whose dimension is a multiple of 4");
+        return HNSW_ERR_ARG;
+    }
+    const uint64_t batch = 2048;  // queries per launch: 64 tiles of 32
+    const uint32_t ntile_max = (uint32_t)(batch / 32);
+    // enough workgroups for the chip (256 CUs, one 98-KB query tile each at d = 768) without cutting the
+    // points into segments shorter than a few tiles per wave
+    // about 768 workgroups per launch (256 CUs, up to three 32-query tiles of a small dimension each), but
+    // no segment shorter than a few point tiles per wave; fewer segments = fewer partial lists to merge
+    const uint32_t ntile_first = (uint32_t)((std::min(batch, nq) + 31) / 32);
+    const uint32_t nseg = (uint32_t)std::max<uint64_t>(
+        1, std::min<uint64_t>(std::max<uint32_t>(1, 768 / ntile_first), (uint64_t)v.n_points / 4096));
+    const uint32_t M = k + 8;
+    const size_t per_tile = (size_t)nseg * 4 * 64 * K2;
+    DevBuf dQ, dXn, dS, dI, dQi, dPi, dOut;
+    if ((rc = dQ.alloc(batch * v.dim * 4)) || (rc = dXn.alloc((size_t)v.n_points * 4)) ||
+        (rc = dS.alloc(ntile_max * per_tile * 4)) || (rc = dI.alloc(ntile_max * per_tile * 4)) ||
+        (rc = dQi.alloc(batch * M * 4)) || (rc = dPi.alloc(batch * M * 4)) || (rc = dOut.alloc(batch * M * 4)))
+        return rc;
+    rc = hx::launch_row_norms(v, dXn.as<float>(), nullptr);
+    if (rc != HNSW_OK) return rc;
+    std::vector<float> hs(ntile_max * per_tile), hd(batch * M);
+    std::vector<uint32_t> hi(ntile_max * per_tile), qidx(batch * M), pidx(batch * M);
+    std::vector<std::pair<float, uint32_t>> cand;
+    for (uint64_t q0 = 0; q0 < nq; q0 += batch) {
+        const uint64_t nb = std::min(batch, nq - q0);
+        const uint32_t ntile = (uint32_t)((nb + 31) / 32);
+        HIP_TRY(hipMemcpy(dQ.p, Q + q0 * v.dim, nb * v.dim * 4, hipMemcpyHostToDevice));
+        rc = hx::launch_brute_mfma(v, dXn.as<float>(), dQ.as<float>(), (uint32_t)nb, nseg, dS.as<float>(),
+                                   dI.as<uint32_t>(), nullptr);
+        if (rc != HNSW_OK) return rc;
+        HIP_TRY(hipMemcpy(hs.data(), dS.p, ntile * per_tile * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hi.data(), dI.p, ntile * per_tile * 4, hipMemcpyDeviceToHost));
+        // per query: the lists of lanes j and j + 32 of every (segment, wave); keep the M best scores
+        for (uint64_t qi = 0; qi < nb; qi++) {
+            const uint32_t tile = (uint32_t)(qi / 32), j = (uint32_t)(qi % 32);
+            cand.clear();
+            for (uint32_t sw = 0; sw < nseg * 4; sw++)
+                for (uint32_t half = 0; half < 2; half++) {
+                    const size_t o = (((size_t)tile * nseg * 4 + sw) * 64 + j + 32 * half) * K2;
+                    for (uint32_t t = 0; t < K2; t++)
+                        if (hi[o + t] != UINT32_MAX) cand.emplace_back(hs[o + t], hi[o + t]);
+                }
+            const size_t keep = std::min<size_t>(M, cand.size());
+            std::partial_sort(cand.begin(), cand.begin() + keep, cand.end());
+            for (uint32_t t = 0; t < M; t++) {
+                qidx[qi * M + t] = (uint32_t)qi;
+                pidx[qi * M + t] = t < keep ? cand[t].second : UINT32_MAX;
+            }
+        }
+        // exact distances of the survivors, in the reference's arithmetic
+        HIP_TRY(hipMemcpy(dQi.p, qidx.data(), nb * M * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dPi.p, pidx.data(), nb * M * 4, hipMemcpyHostToDevice));
+        rc = hx::launch_pair_distance(v, dQ.as<float>(), dQi.as<uint32_t>(), dPi.as<uint32_t>(), nb * M,
+                                      dOut.as<float>(), nullptr);
+        if (rc != HNSW_OK) return rc;
+        HIP_TRY(hipMemcpy(hd.data(), dOut.p, nb * M * 4, hipMemcpyDeviceToHost));
+        for (uint64_t qi = 0; qi < nb; qi++) {
+            cand.clear();
+            for (uint32_t t = 0; t < M; t++) {
+                const uint32_t id = pidx[qi * M + t];
+                if (id == UINT32_MAX) continue;
+                const float dd = hd[qi * M + t];
+                if (dd != dd) {
+                    set_error("NaN in a query or a distance");
+                    return HNSW_ERR_NAN_INPUT;
+                }
+                cand.emplace_back(dd, id);
+            }
+            std::sort(cand.begin(), cand.end());  // (dist, id): Dist::cmp for non-NaN distances
+            for (uint32_t t = 0; t < k; t++) {
+                const bool have = t < cand.size();
+                ids[(q0 + qi) * k + t] = have ? cand[t].second : UINT32_MAX;
+                if (dists) dists[(q0 + qi) * k + t] = have ? cand[t].first : INFINITY;
+            }
+        }
+    }
+    return HNSW_OK;
+}
+
 // ---- accessors -----------------------------------------------------------------------------------
 uint64_t hnsw_len(const hnsw_index *h) { return h ? h->host->len() : 0; }
 

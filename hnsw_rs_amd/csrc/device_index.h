@@ -171,6 +171,15 @@ int launch_remove(const DevView &v, const ConnectArgs &a, hipStream_t stream);
 int launch_scatter_rows(uint32_t *dst, uint32_t S, const uint32_t *d_row_index, const uint32_t *d_data,
                         uint32_t n, hipStream_t stream);
 
+// exhaustive scan on the matrix cores (brute_mfma.hip): a screen by MFMA scores, then exact distances of
+// the survivors.  f32 rows, dimension a multiple of 4.
+uint32_t brute_mfma_k2();
+int launch_row_norms(const DevView &v, float *d_xn, hipStream_t stream);
+int launch_brute_mfma(const DevView &v, const float *d_xn, const float *d_Q, uint32_t nq, uint32_t nseg,
+                      float *out_s, uint32_t *out_i, hipStream_t stream);
+int launch_pair_distance(const DevView &v, const float *d_Q, const uint32_t *d_qidx, const uint32_t *d_pidx, uint64_t n,
+                         float *d_out, hipStream_t stream);
+
 // out[i] = dist(point ids[i], query) for one query; d_q is the raw query (dim floats, device)
 int launch_distance_batch(const DevView &v, const float *d_q, const uint32_t *d_ids, uint64_t k,
                           float *d_out, int32_t *d_status, hipStream_t stream);

@@ -301,6 +301,16 @@ class HNSW:
         check(self._L.hnsw_brute_force(self._h, _p(Q, _f32p), nq, k, _p(ids, _u32p), _p(dists, _f32p)))
         return ids, dists
 
+    def brute_force_fast(self, Q, k):
+        """ground truth on the matrix cores (MFMA screen + exact re-rank of the k + 8 best): f32 rows only;
+        not bit-exact by construction, see include/hnsw_mi355x.h"""
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        nq = Q.shape[0]
+        ids = np.zeros((nq, k), dtype=np.uint32)
+        dists = np.zeros((nq, k), dtype=np.float32)
+        check(self._L.hnsw_brute_force_fast(self._h, _p(Q, _f32p), nq, k, _p(ids, _u32p), _p(dists, _f32p)))
+        return ids, dists
+
     # ---- accessors ------------------------------------------------------------------------------
     def len(self):
         return int(self._L.hnsw_len(self._h))

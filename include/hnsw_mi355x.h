@@ -181,6 +181,15 @@ int hnsw_search_layer(hnsw_index *h, uint32_t layer, const float *q, const uint3
  * brute force: helpers/glove.rs:94-109, template.rs:531-541). */
 int hnsw_brute_force(hnsw_index *h, const float *Q, uint64_t nq, uint32_t k, uint32_t *ids,
                      float *dists);
+/* The same ground truth on the matrix cores, for sizes where the exact scan takes minutes (f32 rows,
+ * dimension a multiple of 4, k <= 12): every point is screened by an MFMA score |x|^2 - 2 x.q
+ * (v_mfma_f32_32x32x2_f32: f32 products and sums, but not FullVec::distance's summation order,
+ * vectors/src/full.rs:23-29), the k + 8 best per query are re-evaluated in the reference's exact
+ * arithmetic and sorted by (dist, id).  NOT bit-exact by construction -- rounding in the screen could in
+ * principle lose a true neighbour; hnsw_brute_force is the exact scan.  An extension: the reference has
+ * no counterpart. */
+int hnsw_brute_force_fast(hnsw_index *h, const float *Q, uint64_t nq, uint32_t k, uint32_t *ids,
+                          float *dists);
 
 /* ---- accessors ----------------------------------------------------------------------------- */
 uint64_t hnsw_len(const hnsw_index *h);                                   /* template.rs:146 */

@@ -60,6 +60,7 @@ extern "C" {
         h: *mut HnswIndex, d_q: *const f32, nq: u64, n: u32, ef: u32, d_ids: *mut u32, d_dists: *mut f32,
         d_counts: *mut u32, d_stats: *mut HnswQueryStats, stream: *mut c_void,
     ) -> c_int;
+    pub fn hnsw_brute_force_fast(h: *mut HnswIndex, q: *const f32, nq: u64, k: u32, ids: *mut u32, dists: *mut f32) -> c_int;
     pub fn hnsw_len(h: *const HnswIndex) -> u64;
     pub fn hnsw_distance(h: *const HnswIndex, a: u32, b: u32, out: *mut f32) -> c_int;
     pub fn hnsw_get_vector(h: *const HnswIndex, id: u32, out: *mut f32) -> c_int;

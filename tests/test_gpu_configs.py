@@ -133,3 +133,33 @@ def test_sharded_device_build_at_256d(tmp_path):
     for k in r0.files:
         assert np.array_equal(r0[k], r1[k]), k
     assert r0["recall"][0] > 0.97
+
+
+@pytest.mark.parametrize("n,d", [(20000, 100), (9000, 128), (6000, 768), (5000, 36)])
+def test_mfma_scan_finds_the_exact_neighbours(n, d):
+    """hnsw_brute_force_fast (MFMA screen + exact re-rank) against the exact scan hnsw_brute_force: same ids,
+    same distance bits on these sets (the fast scan is not exact by construction; this is the check the
+    header promises)"""
+    vs = H.synth_rows(0, 0x5EED0001, 0, n, d)
+    qs = H.synth_rows(0, 0x5EED0002, 0, 100, d)
+    idx = H.HNSW.new(8, 16, d, H.VEC_F32)
+    idx.import_points(vs, np.zeros(n, dtype=np.uint8))
+    idx.import_layer(0, np.arange(n, dtype=np.uint32), np.zeros(n + 1, dtype=np.uint64), np.zeros(0, dtype=np.uint32))
+    idx.set_ep(0)
+    want_ids, want_d = idx.brute_force(qs, 10)
+    got_ids, got_d = idx.brute_force_fast(qs, 10)
+    assert np.array_equal(got_ids, want_ids)
+    assert np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32))
+
+
+def test_mfma_scan_rejects_what_it_does_not_serve():
+    vs = H.synth_rows(0, 1, 0, 500, 50)
+    idx = H.HNSW.new(8, 16, 50, H.VEC_F32)  # 50 is not a multiple of 4
+    idx.import_points(vs, np.zeros(500, dtype=np.uint8))
+    idx.import_layer(0, np.arange(500, dtype=np.uint32), np.zeros(501, dtype=np.uint64), np.zeros(0, dtype=np.uint32))
+    idx.set_ep(0)
+    with pytest.raises(H.HnswError):
+        idx.brute_force_fast(vs[:4], 10)
+    q8 = H.HNSW.new(8, 16, 100).insert_bulk(H.synth_rows(0, 1, 0, 300, 100), 1, False)
+    with pytest.raises(H.HnswError):
+        q8.brute_force_fast(H.synth_rows(0, 2, 0, 4, 100), 10)
