@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(64) k_gather(Args a) {
     for (uint32_t it = 0; it < a.iters; it++) {
         const unsigned long long t0 = __builtin_readcyclecounter();
         uint32_t nb = 0;
-        constexpr bool TWO = (VAR == 0 || VAR == 4);
+        constexpr bool TWO = (VAR == 0 || VAR == 4 || VAR == 8);
         constexpr bool BLOCK = (VAR == 5 || VAR == 6);
         if (!BLOCK) {
             if (TWO || lane < 32 || VAR == 2) {
@@ -126,6 +126,42 @@ __global__ void __launch_bounds__(64) k_gather(Args a) {
                 for (int q = 0; q < 25; q++) {
                     const uint4 w = mine[q];
                     x ^= w.x ^ w.w;
+                }
+            }
+            wait_lgkm0();
+        } else if (VAR == 7 || VAR == 8) {
+            // image order through registers: lane l of load k fetches piece 64 k + l of the row-major image
+            // (a row's 25 pieces are contiguous lanes: ~3 rows per instruction instead of 64), writes it to
+            // LDS, then the row lanes read their rows back
+            constexpr int NR = (VAR == 7) ? 32 : 64;
+            constexpr int NI = (NR * 25 + 63) / 64;
+            ids_lds[lane] = nb;
+            wait_lgkm0();
+            uint32_t r = (uint32_t)lane / 25u, pc = (uint32_t)lane % 25u;
+            uint4 w[NI];
+#pragma unroll
+            for (int k = 0; k < NI; k++) {
+                const uint32_t rr = r < NR ? r : NR - 1;
+                const uint32_t id = ids_lds[rr];
+                w[k] = *reinterpret_cast<const uint4 *>(a.rows + (size_t)id * 400 + 16 * pc);
+                pc += 14;
+                r += 2;
+                if (pc >= 25) {
+                    pc -= 25;
+                    r += 1;
+                }
+            }
+            wait_vm0();
+#pragma unroll
+            for (int k = 0; k < NI; k++) *reinterpret_cast<uint4 *>(img + 1024 * k + 16 * lane) = w[k];
+            wait_lgkm0();
+            t2 = __builtin_readcyclecounter();
+            if (lane < NR) {
+                const uint4 *mine = reinterpret_cast<const uint4 *>(img + 400 * lane);
+#pragma unroll
+                for (int q = 0; q < 25; q++) {
+                    const uint4 ww = mine[q];
+                    x ^= ww.x ^ ww.w;
                 }
             }
             wait_lgkm0();
@@ -257,6 +293,8 @@ int main(int argc, char **argv) {
         run<2>(a, nw, "2 lane-pair/row, 32 rows", 32 * 400 + 128);
         run<3>(a, nw, "3 DMA image, 32 rows + LDS reads", 32 * 400 + 128);
         run<4>(a, nw, "4 DMA image, 64 rows + LDS reads", 64 * 400 + 256);
+        run<7>(a, nw, "7 image order via registers, 32 rows", 32 * 400 + 128);
+        run<8>(a, nw, "8 image order via registers, 64 rows", 64 * 400 + 256);
         if (blocks) {
             run<5>(a, nw, "5 contiguous 12.8 KB block -> regs", 12800);
             run<6>(a, nw, "6 contiguous block DMA -> LDS + reads", 12800);
