@@ -307,22 +307,24 @@ struct Lst {
 // FullVec::distance of one row per lane against the query held in registers (full.rs:23-29): x - y and
 // the square two elements per instruction (each element the same single-rounded IEEE operations), the
 // sum one serial chain in element order
+// the row of this lane: all DS / 4 pieces requested at once
 template <int DS>
-__device__ __forceinline__ float row_dist(const float *rows, uint32_t id, bool want, const float (&qv)[DS],
-                                          unsigned long long *t_landed = nullptr) {
-    constexpr int P = DS / 4;
-    float s = 0.0f;
+__device__ __forceinline__ void row_fetch(const float *rows, uint32_t id, bool want, uint4 (&w)[DS / 4]) {
     if (want) {
         const uint4 *src = reinterpret_cast<const uint4 *>(rows + (size_t)id * DS);
-        uint4 w[P];
 #pragma unroll
-        for (int p = 0; p < P; p++) w[p] = src[p];
-        __builtin_amdgcn_sched_barrier(0);  // every piece requested before the chain starts
-#ifdef HX_STAMPS
-        if (t_landed) *t_landed = stamp_now();
-#endif
+        for (int p = 0; p < DS / 4; p++) w[p] = src[p];
+    }
+}
+// FullVec::distance of the fetched row against the query held in registers (full.rs:23-29): x - y and the
+// square two elements per instruction (each element the same single-rounded IEEE operations), the sum one
+// serial chain in element order
+template <int DS>
+__device__ __forceinline__ float row_chain(const uint4 (&w)[DS / 4], bool want, const float (&qv)[DS]) {
+    float s = 0.0f;
+    if (want) {
 #pragma unroll
-        for (int p = 0; p < P; p++) {
+        for (int p = 0; p < DS / 4; p++) {
             const uint32_t dw[4] = {w[p].x, w[p].y, w[p].z, w[p].w};
 #pragma unroll
             for (int j = 0; j < 4; j += 2) {
@@ -336,6 +338,17 @@ __device__ __forceinline__ float row_dist(const float *rows, uint32_t id, bool w
         }
     }
     return __builtin_sqrtf(s);
+}
+template <int DS>
+__device__ __forceinline__ float row_dist(const float *rows, uint32_t id, bool want, const float (&qv)[DS],
+                                          unsigned long long *t_landed = nullptr) {
+    uint4 w[DS / 4];
+    row_fetch<DS>(rows, id, want, w);
+    __builtin_amdgcn_sched_barrier(0);  // every piece requested before the chain starts
+#ifdef HX_STAMPS
+    if (t_landed) *t_landed = stamp_now();
+#endif
+    return row_chain<DS>(w, want, qv);
 }
 
 template <int DS, int R>
@@ -550,6 +563,14 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
             const uint32_t vb = vis.home(nb);
             const uint32_t vt0 = vis.look(nb, vb);
             const uint32_t vt = valid ? vt0 : 4u;       // 0..3 claimable slot, 4 nothing to do, 5 bucket full
+            // The rows are requested as soon as the look says "absent" -- for c's lanes that is exactly the
+            // set that ends up inserted, barring the rare id that sits in a later bucket of a full home
+            // bucket -- and the claims (a second LDS round trip and the loop of the lanes that lost a slot)
+            // run while the rows are on their way.
+            const bool want_pre = vt != 4u;
+            uint4 w[DS / 4];
+            row_fetch<DS>(a.rows, nb, want_pre, w);
+            __builtin_amdgcn_sched_barrier(0);
             const uint32_t ct = upper ? 4u : vt;
             const uint32_t old = vis.claim(nb, vb, ct);
             bool fresh = old == HX_EMPTY_SLOT;          // c's lanes that inserted their id
@@ -560,7 +581,7 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
                 dbg_acc[11]++;
 #endif
             }
-            const bool want = upper ? (vt != 4u) : fresh;
+            const bool want = upper ? want_pre : fresh;
             const u64 vmask = __ballot(valid), fmask = __ballot(fresh);
             const uint32_t cnt_c = (uint32_t)__popcll(vmask & 0xFFFFFFFFull);
             const uint32_t cnt_p = (uint32_t)__popcll(vmask >> 32);
@@ -581,11 +602,7 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
             unsigned long long t_landed = f2;
 #endif
             if (__ballot(want)) {
-#ifdef HX_STAMPS
-                const float dist = row_dist<DS>(a.rows, nb, want, qv, &t_landed);
-#else
-                const float dist = row_dist<DS>(a.rows, nb, want, qv);
-#endif
+                const float dist = row_chain<DS>(w, want, qv);
                 nan = want && dist != dist;
                 if (want && !nan) key = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | nb;
             }
@@ -926,7 +943,8 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
 
         // One candidate per pass.  (Evaluating the runner-up as well -- its rows fetched together with
         // c's, its chain run when it is committed -- was built, parity-tested and measured slower:
-        // 0.196 against 0.180 ms per batch at efSearch 68.)
+        // 0.196 against 0.180 ms per batch at efSearch 68.  So was requesting the rows right after the
+        // look, before the claim, which pays for the f32 rows' 25 loads: 0.186 against 0.180 ms here.)
         while (true) {
             u64 U[R];
             lst.unexp_masks(U);
