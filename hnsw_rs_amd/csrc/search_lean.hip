@@ -265,40 +265,63 @@ struct Lst {
             }
             return;
         }
-        // rank of every survivor among list + survivors, shift of every list entry; scatter via LDS
+        // Three or more.  One loop over the survivors, no vector -> scalar hand-off in it: every list
+        // entry counts the survivors that sort before it (its shift), every survivor its rank among the
+        // survivors.  The list entries then go to their final places through LDS; the places nobody wrote
+        // are the survivors', in order: the s-th hole takes the survivor of rank s (sv[], filled on the
+        // way).  perm holds 64 R entries, sv the 64 behind them.
+        u64 *sv = perm + 64 * R;
+        u64 Lm[R];
         uint32_t shift[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) shift[r] = 0;
-        uint32_t my_rank = 0;
+        for (int r = 0; r < R; r++) {
+            Lm[r] = L[r] & LK_MASK;
+            shift[r] = 0;
+        }
+        uint32_t srank = 0;
         u64 it = smask;
         while (it) {
             const uint32_t j = (uint32_t)__ffsll((long long)it) - 1;
             it &= it - 1;
             const u64 e = rdlane64(key, j);
-            uint32_t below = 0;
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const bool lt = (L[r] & LK_MASK) < e;
-                below += (uint32_t)__popcll(__ballot(lt));
-                shift[r] += lt ? 0u : 1u;
-            }
-            if (surv && e < key) my_rank++;
-            if ((uint32_t)lane == j) my_rank += below;
+            for (int r = 0; r < R; r++) shift[r] += e < Lm[r] ? 1u : 0u;
+            srank += e < key ? 1u : 0u;
         }
+        const uint32_t n_new = min(n_cur + m, ef);
+#pragma unroll
+        for (int r = 0; r < R; r++) perm[R * lane + r] = LK_INVALID;
+        asm volatile("" ::: "memory");  // LDS serves a wave's requests in order
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t idx = (uint32_t)(R * lane + r);
             const uint32_t np = idx + shift[r];
-            if (idx < n_cur && np < ef) perm[np] = L[r];
+            if (idx < n_cur && np < n_new) perm[np] = L[r];
         }
-        if (surv && my_rank < ef) perm[my_rank] = key;
-        n_cur = min(n_cur + m, ef);
-        lds_fence();
+        if (surv) sv[srank] = key;
+        asm volatile("" ::: "memory");
+        u64 v[R], H[R];
+        bool hole[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = perm[R * lane + r];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const uint32_t idx = (uint32_t)(R * lane + r);
-            L[r] = idx < n_cur ? perm[idx] : LK_INVALID;
+            hole[r] = v[r] == LK_INVALID && (uint32_t)(R * lane + r) < n_new;
+            H[r] = __ballot(hole[r]);
         }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            uint32_t hr = 0;  // holes at places before R * lane + r
+#pragma unroll
+            for (int r2 = 0; r2 < R; r2++) {
+                hr += __builtin_amdgcn_mbcnt_hi((uint32_t)(H[r2] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)H[r2], 0u));
+                if (r2 < r && hole[r2]) hr++;
+            }
+            if (hole[r]) v[r] = sv[hr];
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) L[r] = v[r];
+        n_cur = n_new;
         lds_fence();
         refresh_last(ef);
     }
@@ -534,8 +557,15 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
             const int cpos = Lst<R>::take_first(U);
             if (cpos < 0) break;  // candidates exhausted / only worse ones left (searcher.rs:35,41-44)
             const int ppos = Lst<R>::take_first(U);
+            // the two entries after the pair: what the NEXT pass will most likely expand (see below)
+            const int apos = ppos >= 0 ? Lst<R>::take_first(U) : -1;
+            const int bpos = apos >= 0 ? Lst<R>::take_first(U) : -1;
             const uint32_t cid = lst.id_at((uint32_t)cpos);
-            const uint32_t pid = ppos >= 0 ? lst.id_at((uint32_t)ppos) : HX_EMPTY_SLOT;
+            const u64 pkey = ppos >= 0 ? (lst.key_at((uint32_t)ppos) & LK_MASK) : 0;
+            const uint32_t pid = ppos >= 0 ? (uint32_t)pkey : HX_EMPTY_SLOT;
+            const uint32_t aid = apos >= 0 ? lst.id_at((uint32_t)apos) : HX_EMPTY_SLOT;
+            const u64 bkey = bpos >= 0 ? (lst.key_at((uint32_t)bpos) & LK_MASK) : lst.last_key;
+            const uint32_t bid = bpos >= 0 ? (uint32_t)bkey : HX_EMPTY_SLOT;
             lst.mark((uint32_t)cpos, lane);
             n_exp++;
             uint32_t nb;
@@ -545,7 +575,14 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
                 nb = HX_EMPTY_SLOT;
                 if (slot < S0 && (!upper || ppos >= 0)) nb = a.adj0[(size_t)(upper ? pid : cid) * S0 + slot];
             }
-            pre_c = HX_EMPTY_SLOT;
+            // If the runner-up is committed in this pass, the next pass will most likely expand the two
+            // entries that follow it.  Their adjacency rows are requested now, with the ids as they stand at
+            // the pick (cheaper than looking again after the merge, and earlier); if the next pick is a
+            // different pair they are dropped.
+            pre_c = aid;
+            pre_p = bid;
+            pre_nb = HX_EMPTY_SLOT;
+            if (apos >= 0 && slot < S0 && (!upper || bpos >= 0)) pre_nb = a.adj0[(size_t)(upper ? bid : aid) * S0 + slot];
 #ifdef HX_STAMPS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             dbg_acc[6]++;
@@ -620,6 +657,9 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
                 status = HNSW_ERR_NAN_INPUT;  // Dist::cmp would panic (dist.rs:32)
                 break;
             }
+            // (an overflow row of c is rare: no speculation in that pass)
+            const bool p_next = spec_ok && pm == 0 && __ballot(!upper && key < pkey) == 0;
+            const bool re_predict = __ballot(!upper && key < bkey) != 0;
             lst.merge(upper ? LK_INVALID : key, ef, perm, lane);
             STAMP(f3b);
             STAMP_ADD(8, f3, f3b);
@@ -651,29 +691,24 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
                 }
                 if (status != HNSW_OK) break;
             }
-            // ---- is p the next candidate?  then commit it from the registers ----
-            if (!spec_ok) continue;
-            u64 V[R];
-            lst.unexp_masks(V);
-            const int npos = Lst<R>::take_first(V);
-            if (npos < 0) break;
-            if (lst.id_at((uint32_t)npos) != pid) continue;
-            // The pass after this one will most likely expand the two entries that follow p (measured:
-            // three times out of four when p is committed).  Their adjacency rows are requested now and
-            // land while p is being committed; if the next pick is a different pair they are dropped.
-            {
-                const int apos = Lst<R>::take_first(V);
-                if (apos >= 0) {
-                    const int bpos = Lst<R>::take_first(V);
-                    pre_c = lst.id_at((uint32_t)apos);
-                    pre_p = bpos >= 0 ? lst.id_at((uint32_t)bpos) : HX_EMPTY_SLOT;
-                    pre_nb = HX_EMPTY_SLOT;
-                    if (slot < S0 && (!upper || bpos >= 0)) pre_nb = a.adj0[(size_t)(upper ? pre_p : pre_c) * S0 + slot];
-                }
+            // ---- is p the next candidate?  It is unless something c brought in sorts before it (p was the
+            // first unexpanded entry after c; entries only move behind an insertion point, so p also still
+            // sits at ppos).  Then commit it from the registers. ----
+            if (!p_next) continue;
+            if (re_predict) {  // something c brought in sorts before b: the pair after p is a different one
+                u64 V[R];
+                lst.unexp_masks(V);
+                (void)Lst<R>::take_first(V);  // p
+                const int a2 = Lst<R>::take_first(V);
+                const int b2 = a2 >= 0 ? Lst<R>::take_first(V) : -1;
+                pre_c = a2 >= 0 ? lst.id_at((uint32_t)a2) : HX_EMPTY_SLOT;
+                pre_p = b2 >= 0 ? lst.id_at((uint32_t)b2) : HX_EMPTY_SLOT;
+                pre_nb = HX_EMPTY_SLOT;
+                if (a2 >= 0 && slot < S0 && (!upper || b2 >= 0)) pre_nb = a.adj0[(size_t)(upper ? pre_p : pre_c) * S0 + slot];
             }
             STAMP(f4);
             STAMP_ADD(9, f3b, f4);
-            lst.mark((uint32_t)npos, lane);
+            lst.mark((uint32_t)ppos, lane);
             n_exp++;
             // Every valid neighbour of p goes through the filter now.  The bucket state seen while
             // speculating is still good for a direct claim: slots fill left to right, so if slot vt is
@@ -766,7 +801,7 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
     const uint32_t q = a.qsel ? a.qsel[blockIdx.x] : blockIdx.x;
     const uint32_t hslots = 1u << a.slots_log2;
     u64 *perm = reinterpret_cast<u64 *>(smem + 4ull * hslots);
-    float *yq = reinterpret_cast<float *>(perm + 64 * R);
+    float *yq = reinterpret_cast<float *>(perm + 64 * R + 64);  // behind the merge's two areas
     Visited vis;
     vis.tab = reinterpret_cast<uint32_t *>(smem);
     const uint8_t *rows8 = reinterpret_cast<const uint8_t *>(a.rows);
@@ -1062,7 +1097,7 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
 
 template <int R>
 int launch_lean_q8(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
-    const size_t lds = (4ull << a.slots_log2) + 64ull * R * 8 + 2 * 56 * 4;
+    const size_t lds = (4ull << a.slots_log2) + (64ull * R + 64) * 8 + 2 * 56 * 4;
     auto kern = hx_lean_q8_kernel<R>;
     if (lds > 160 * 1024) {
         set_error("search needs %zu bytes of LDS (> 160 KiB)", lds);
@@ -1087,7 +1122,7 @@ int launch_lean_q8(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
 
 template <int DS, int R>
 int launch_lean_one(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
-    const size_t lds = (4ull << a.slots_log2) + 64ull * R * 8;
+    const size_t lds = (4ull << a.slots_log2) + (64ull * R + 64) * 8;
     auto kern = hx_lean_f32_kernel<DS, R>;
     if (lds > 160 * 1024) {
         set_error("search needs %zu bytes of LDS (> 160 KiB)", lds);

@@ -43,3 +43,15 @@ for ef in efs:
     print('   unaccounted %.1f%%' % (100 * (tot.mean() - acc) / tot.mean()))
     print('   per query: visited slow-loop rounds %.1f; merges with 0 / 1-2 / >=3 survivors: %.1f / %.1f / %.1f; p commits %.1f' % (
         D[:, 11].mean(), D[:, 12].mean(), D[:, 13].mean(), D[:, 14].mean(), D[:, 15].mean()))
+    # what do the slowest queries look like?  (the kernel lasts as long as its slowest wave)
+    order = np.argsort(-tot)[:8]
+    print('   slowest queries: total cycles, n_exp, n_dist, passes, cycles/pass, slow-loop rounds, merges 0/1-2/>=3, p commits')
+    for qi in order:
+        print('     q%-5d %8.0f  n_exp %4d n_dist %5d passes %4d  %6.0f/pass  slow %3d  merges %3d/%3d/%3d  pcommits %3d' % (
+            qi, tot[qi], S[qi, 1], S[qi, 0], passes[qi], tot[qi] / max(1, passes[qi]), D[qi, 11], D[qi, 12], D[qi, 13], D[qi, 14], D[qi, 15]))
+    cc = np.corrcoef(tot, S[:, 1])[0, 1]
+    fit = np.polyfit(S[:, 1].astype(np.float64), tot, 1)
+    print('   corr(total cycles, n_exp) = %.3f; fit: cycles = %.0f * n_exp + %.0f; n_exp mean %.1f p99 %.0f max %d' % (
+        cc, fit[0], fit[1], S[:, 1].mean(), np.percentile(S[:, 1], 99), S[:, 1].max()))
+    res = tot - np.polyval(fit, S[:, 1].astype(np.float64))
+    print('   residual of that fit: std %.0f, max %.0f, min %.0f' % (res.std(), res.max(), res.min()))
