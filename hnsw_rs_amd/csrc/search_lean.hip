@@ -560,15 +560,8 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
             const int cpos = Lst<R>::take_first(U);
             if (cpos < 0) break;  // candidates exhausted / only worse ones left (searcher.rs:35,41-44)
             const int ppos = Lst<R>::take_first(U);
-            // the two entries after the pair: what the NEXT pass will most likely expand (see below)
-            const int apos = ppos >= 0 ? Lst<R>::take_first(U) : -1;
-            const int bpos = apos >= 0 ? Lst<R>::take_first(U) : -1;
             const uint32_t cid = lst.id_at((uint32_t)cpos);
-            const u64 pkey = ppos >= 0 ? (lst.key_at((uint32_t)ppos) & LK_MASK) : 0;
-            const uint32_t pid = ppos >= 0 ? (uint32_t)pkey : HX_EMPTY_SLOT;
-            const uint32_t aid = apos >= 0 ? lst.id_at((uint32_t)apos) : HX_EMPTY_SLOT;
-            const u64 bkey = bpos >= 0 ? (lst.key_at((uint32_t)bpos) & LK_MASK) : lst.last_key;
-            const uint32_t bid = bpos >= 0 ? (uint32_t)bkey : HX_EMPTY_SLOT;
+            const uint32_t pid = ppos >= 0 ? lst.id_at((uint32_t)ppos) : HX_EMPTY_SLOT;
             lst.mark((uint32_t)cpos, lane);
             n_exp++;
             uint32_t nb;
@@ -578,14 +571,7 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
                 nb = HX_EMPTY_SLOT;
                 if (slot < S0 && (!upper || ppos >= 0)) nb = a.adj0[(size_t)(upper ? pid : cid) * S0 + slot];
             }
-            // If the runner-up is committed in this pass, the next pass will most likely expand the two
-            // entries that follow it.  Their adjacency rows are requested now, with the ids as they stand at
-            // the pick (cheaper than looking again after the merge, and earlier); if the next pick is a
-            // different pair they are dropped.
-            pre_c = aid;
-            pre_p = bid;
-            pre_nb = HX_EMPTY_SLOT;
-            if (apos >= 0 && slot < S0 && (!upper || bpos >= 0)) pre_nb = a.adj0[(size_t)(upper ? bid : aid) * S0 + slot];
+            pre_c = HX_EMPTY_SLOT;
 #ifdef HX_STAMPS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             dbg_acc[6]++;
@@ -660,9 +646,6 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
                 status = HNSW_ERR_NAN_INPUT;  // Dist::cmp would panic (dist.rs:32)
                 break;
             }
-            // (an overflow row of c is rare: no speculation in that pass)
-            const bool p_next = spec_ok && pm == 0 && __ballot(!upper && key < pkey) == 0;
-            const bool re_predict = __ballot(!upper && key < bkey) != 0;
             lst.merge(upper ? LK_INVALID : key, ef, perm, lane);
             STAMP(f3b);
             STAMP_ADD(8, f3, f3b);
@@ -694,24 +677,29 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
                 }
                 if (status != HNSW_OK) break;
             }
-            // ---- is p the next candidate?  It is unless something c brought in sorts before it (p was the
-            // first unexpanded entry after c; entries only move behind an insertion point, so p also still
-            // sits at ppos).  Then commit it from the registers. ----
-            if (!p_next) continue;
-            if (re_predict) {  // something c brought in sorts before b: the pair after p is a different one
-                u64 V[R];
-                lst.unexp_masks(V);
-                (void)Lst<R>::take_first(V);  // p
-                const int a2 = Lst<R>::take_first(V);
-                const int b2 = a2 >= 0 ? Lst<R>::take_first(V) : -1;
-                pre_c = a2 >= 0 ? lst.id_at((uint32_t)a2) : HX_EMPTY_SLOT;
-                pre_p = b2 >= 0 ? lst.id_at((uint32_t)b2) : HX_EMPTY_SLOT;
-                pre_nb = HX_EMPTY_SLOT;
-                if (a2 >= 0 && slot < S0 && (!upper || b2 >= 0)) pre_nb = a.adj0[(size_t)(upper ? pre_p : pre_c) * S0 + slot];
+            // ---- is p the next candidate?  then commit it from the registers ----
+            if (!spec_ok) continue;
+            u64 V[R];
+            lst.unexp_masks(V);
+            const int npos = Lst<R>::take_first(V);
+            if (npos < 0) break;
+            if (lst.id_at((uint32_t)npos) != pid) continue;
+            // The pass after this one will most likely expand the two entries that follow p (measured:
+            // three times out of four when p is committed).  Their adjacency rows are requested now and
+            // land while p is being committed; if the next pick is a different pair they are dropped.
+            {
+                const int apos = Lst<R>::take_first(V);
+                if (apos >= 0) {
+                    const int bpos = Lst<R>::take_first(V);
+                    pre_c = lst.id_at((uint32_t)apos);
+                    pre_p = bpos >= 0 ? lst.id_at((uint32_t)bpos) : HX_EMPTY_SLOT;
+                    pre_nb = HX_EMPTY_SLOT;
+                    if (slot < S0 && (!upper || bpos >= 0)) pre_nb = a.adj0[(size_t)(upper ? pre_p : pre_c) * S0 + slot];
+                }
             }
             STAMP(f4);
             STAMP_ADD(9, f3b, f4);
-            lst.mark((uint32_t)ppos, lane);
+            lst.mark((uint32_t)npos, lane);
             n_exp++;
             // Every valid neighbour of p goes through the filter now.  The bucket state seen while
             // speculating is still good for a direct claim: slots fill left to right, so if slot vt is

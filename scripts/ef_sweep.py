@@ -1,9 +1,10 @@
-"""batch-1024 time per efSearch on the 1M x 100d index (gpurun): usage kind ef..."""
+"""batch-1024 time per efSearch on the 1M x 100d index (gpurun): usage: f32|q8 ef..."""
 import os, sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
 import hnsw_rs_amd as H
-kind = int(sys.argv[1]); efs = [int(x) for x in sys.argv[2:]]
+kind = {'f32': H.VEC_F32, 'q8': H.VEC_QUANT8}[sys.argv[1]]  # by name: the enum is QUANT8 = 0, F32 = 1
+efs = [int(x) for x in sys.argv[2:]]
 N, d, m, B, n = 1000000, 100, 16, 1024, 10
 vs = H.synth_rows(0, 0x5EED0001, 0, N, d, 32); qs = H.synth_rows(0, 0x5EED0002, 0, 8 * B, d, 8)
 idx = H.HNSW.new(m, 32, d, kind); idx.insert_bulk_device(vs, 32, False); idx.upload()
@@ -22,4 +23,4 @@ for ef in efs:
         for b in range(8): run(b)
     e1.record(); torch.cuda.synchronize(); ms = e0.elapsed_time(e1) / 32
     s = st.cpu().numpy()
-    print('kind=%d ef=%d  %.4f ms/batch  %.2f M q/s  n_dist %.0f n_exp %.1f  us/exp %.2f' % (kind, ef, ms, B / ms / 1e3, s[:, 0].mean(), s[:, 1].mean(), ms * 1e3 / s[:, 1].mean()), flush=True)
+    print('kind=%s ef=%d  %.4f ms/batch  %.2f M q/s  n_dist %.0f n_exp %.1f  us/exp %.2f' % (sys.argv[1], ef, ms, B / ms / 1e3, s[:, 0].mean(), s[:, 1].mean(), ms * 1e3 / s[:, 1].mean()), flush=True)
