@@ -552,26 +552,38 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
         // the adjacency rows fetched ahead for the pass after this one (see below)
         uint32_t pre_nb = HX_EMPTY_SLOT, pre_c = HX_EMPTY_SLOT, pre_p = HX_EMPTY_SLOT;
 
+        // the part of c's row that did not fit its S0 slots (degree > S0, rare), 32 ids per pass
+        uint32_t ovf_lo = 0, ovf_hi = 0;
+
         while (true) {
-            // ---- pick c (the smallest unexpanded entry) and the runner-up p: one set of ballots ----
             STAMP(f0);
-            u64 U[R];
-            lst.unexp_masks(U);
-            const int cpos = Lst<R>::take_first(U);
-            if (cpos < 0) break;  // candidates exhausted / only worse ones left (searcher.rs:35,41-44)
-            const int ppos = Lst<R>::take_first(U);
-            const uint32_t cid = lst.id_at((uint32_t)cpos);
-            const uint32_t pid = ppos >= 0 ? lst.id_at((uint32_t)ppos) : HX_EMPTY_SLOT;
-            lst.mark((uint32_t)cpos, lane);
-            n_exp++;
-            uint32_t nb;
-            if (pre_c == cid && pre_p == pid) {
-                nb = pre_nb;  // both rows were requested during the previous pass
+            int ppos = -1;
+            uint32_t pid = HX_EMPTY_SLOT;
+            uint32_t nb = HX_EMPTY_SLOT;
+            const bool ovf_pass = ovf_lo < ovf_hi;
+            if (ovf_pass) {
+                // ---- more of the last candidate's neighbours: the same pass without a pick and without
+                // a runner-up (one body for both keeps a single set of row registers in the loop) ----
+                if (lane < 32 && ovf_lo + (uint32_t)lane < ovf_hi) nb = a.ovf_nbrs[ovf_lo + (uint32_t)lane];
+                ovf_lo += 32;
             } else {
-                nb = HX_EMPTY_SLOT;
-                if (slot < S0 && (!upper || ppos >= 0)) nb = a.adj0[(size_t)(upper ? pid : cid) * S0 + slot];
+                // ---- pick c (the smallest unexpanded entry) and the runner-up p: one set of ballots ----
+                u64 U[R];
+                lst.unexp_masks(U);
+                const int cpos = Lst<R>::take_first(U);
+                if (cpos < 0) break;  // candidates exhausted / only worse ones left (searcher.rs:35,41-44)
+                ppos = Lst<R>::take_first(U);
+                const uint32_t cid = lst.id_at((uint32_t)cpos);
+                if (ppos >= 0) pid = lst.id_at((uint32_t)ppos);
+                lst.mark((uint32_t)cpos, lane);
+                n_exp++;
+                if (pre_c == cid && pre_p == pid) {
+                    nb = pre_nb;  // both rows were requested during the previous pass
+                } else {
+                    if (slot < S0 && (!upper || ppos >= 0)) nb = a.adj0[(size_t)(upper ? pid : cid) * S0 + slot];
+                }
+                pre_c = HX_EMPTY_SLOT;
             }
-            pre_c = HX_EMPTY_SLOT;
 #ifdef HX_STAMPS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             dbg_acc[6]++;
@@ -580,7 +592,7 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
             STAMP_ADD(0, f0, f1);
             // ---- classify the slots.  A row with an overflow pointer (degree > S0) is rare: c's is
             // finished after the merge, a runner-up with one is not speculated on ----
-            const u64 pm = __ballot((int32_t)nb < -1);  // 0x80000000 | overflow row
+            const u64 pm = ovf_pass ? 0ull : __ballot((int32_t)nb < -1);  // 0x80000000 | overflow row
             const bool spec_ok = ppos >= 0 && (pm >> 32) == 0;
             const bool valid = (int32_t)nb >= 0 && (!upper || spec_ok);
             // ---- visited: every lane looks at its home bucket; c's lanes claim a slot, p's lanes only
@@ -649,33 +661,11 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
             lst.merge(upper ? LK_INVALID : key, ef, perm, lane);
             STAMP(f3b);
             STAMP_ADD(8, f3, f3b);
-            if (pm & 0xFFFFFFFFull) {  // degree > S0: the rest of c's row (rare)
+            if (pm & 0xFFFFFFFFull) {  // degree > S0: the rest of c's row goes through the next passes (rare)
                 const uint32_t c_ovf = rdlane(nb, (uint32_t)__ffsll((long long)(pm & 0xFFFFFFFFull)) - 1) & ~HX_OVF_FLAG;
-                const uint32_t lo = uni(a.ovf_off[c_ovf]), hi = uni(a.ovf_off[c_ovf + 1]);
-                for (uint32_t base = lo; base < hi && status == HNSW_OK; base += 32) {
-                    const uint32_t i = base + lane;
-                    const bool ov = lane < 32 && i < hi;
-                    const uint32_t onb = ov ? a.ovf_nbrs[i] : HX_EMPTY_SLOT;
-                    const uint32_t ocnt = (uint32_t)__popcll(__ballot(ov));
-                    sum_deg += ocnt;
-                    if (n_vis + ocnt > vis_limit) {
-                        status = HNSW_ERR_OVERFLOW;
-                        break;
-                    }
-                    const bool ofresh = vis.insert(onb, ov);
-                    const uint32_t onf = (uint32_t)__popcll(__ballot(ofresh));
-                    n_vis += onf;
-                    n_dist += onf;
-                    if (onf == 0) continue;
-                    const float odist = row_dist<DS>(a.rows, onb, ofresh, qv);
-                    if (__ballot(ofresh && odist != odist)) {
-                        status = HNSW_ERR_NAN_INPUT;
-                        break;
-                    }
-                    lst.merge(ofresh ? (((u64)__builtin_bit_cast(uint32_t, odist) << 32) | onb) : LK_INVALID, ef,
-                              perm, lane);
-                }
-                if (status != HNSW_OK) break;
+                ovf_lo = uni(a.ovf_off[c_ovf]);
+                ovf_hi = uni(a.ovf_off[c_ovf + 1]);
+                if (ovf_lo < ovf_hi) continue;  // (the runner-up is picked again afterwards)
             }
             // ---- is p the next candidate?  then commit it from the registers ----
             if (!spec_ok) continue;
