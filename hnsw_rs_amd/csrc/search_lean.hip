@@ -332,49 +332,39 @@ struct Lst {
 
 // FullVec::distance of one row per lane against the query held in registers (full.rs:23-29): x - y and
 // the square two elements per instruction (each element the same single-rounded IEEE operations), the
-// sum one serial chain in element order
-// the row of this lane: all DS / 4 pieces requested at once
+// sum one serial chain in element order.  No exec mask of its own: the callers request the row's DS / 4
+// pieces, run this and keep the result under ONE mask (row registers defined under one mask and consumed
+// under another are live across the join for the allocator: 256 VGPRs + 84 AGPRs instead of 234).
 template <int DS>
-__device__ __forceinline__ void row_fetch(const float *rows, uint32_t id, bool want, uint4 (&w)[DS / 4]) {
-    if (want) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(rows + (size_t)id * DS);
-#pragma unroll
-        for (int p = 0; p < DS / 4; p++) w[p] = src[p];
-    }
-}
-// FullVec::distance of the fetched row against the query held in registers (full.rs:23-29): x - y and the
-// square two elements per instruction (each element the same single-rounded IEEE operations), the sum one
-// serial chain in element order
-template <int DS>
-__device__ __forceinline__ float row_chain(const uint4 (&w)[DS / 4], bool want, const float (&qv)[DS]) {
+__device__ __forceinline__ float chain_sum(const uint4 (&w)[DS / 4], const float (&qv)[DS]) {
     float s = 0.0f;
-    if (want) {
 #pragma unroll
-        for (int p = 0; p < DS / 4; p++) {
-            const uint32_t dw[4] = {w[p].x, w[p].y, w[p].z, w[p].w};
+    for (int p = 0; p < DS / 4; p++) {
+        const uint32_t dw[4] = {w[p].x, w[p].y, w[p].z, w[p].w};
 #pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                const f32x2 x = {__builtin_bit_cast(float, dw[j]), __builtin_bit_cast(float, dw[j + 1])};
-                const f32x2 y = {qv[4 * p + j], qv[4 * p + j + 1]};
-                const f32x2 t = x - y;
-                const f32x2 t2 = t * t;
-                s += t2.x;
-                s += t2.y;
-            }
+        for (int j = 0; j < 4; j += 2) {
+            const f32x2 x = {__builtin_bit_cast(float, dw[j]), __builtin_bit_cast(float, dw[j + 1])};
+            const f32x2 y = {qv[4 * p + j], qv[4 * p + j + 1]};
+            const f32x2 t = x - y;
+            const f32x2 t2 = t * t;
+            s += t2.x;
+            s += t2.y;
         }
     }
-    return __builtin_sqrtf(s);
+    return s;
 }
 template <int DS>
-__device__ __forceinline__ float row_dist(const float *rows, uint32_t id, bool want, const float (&qv)[DS],
-                                          unsigned long long *t_landed = nullptr) {
-    uint4 w[DS / 4];
-    row_fetch<DS>(rows, id, want, w);
-    __builtin_amdgcn_sched_barrier(0);  // every piece requested before the chain starts
-#ifdef HX_STAMPS
-    if (t_landed) *t_landed = stamp_now();
-#endif
-    return row_chain<DS>(w, want, qv);
+__device__ __forceinline__ float row_dist(const float *rows, uint32_t id, bool want, const float (&qv)[DS]) {
+    float s = 0.0f;
+    if (want) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(rows + (size_t)id * DS);
+        uint4 w[DS / 4];
+#pragma unroll
+        for (int p = 0; p < DS / 4; p++) w[p] = src[p];
+        __builtin_amdgcn_sched_barrier(0);  // every piece requested before the chain starts
+        s = chain_sum<DS>(w, qv);
+    }
+    return __builtin_sqrtf(s);
 }
 
 template <int DS, int R>
@@ -606,18 +596,33 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
             // bucket -- and the claims (a second LDS round trip and the loop of the lanes that lost a slot)
             // run while the rows are on their way.
             const bool want_pre = vt != 4u;
-            uint4 w[DS / 4];
-            row_fetch<DS>(a.rows, nb, want_pre, w);
-            __builtin_amdgcn_sched_barrier(0);
             const uint32_t ct = upper ? 4u : vt;
-            const uint32_t old = vis.claim(nb, vb, ct);
-            bool fresh = old == HX_EMPTY_SLOT;          // c's lanes that inserted their id
-            const bool pend = (ct != 4u) & !fresh;
-            if (__ballot(pend)) {
-                fresh = vis.finish(nb, vb, ct, pend, fresh);
+            bool fresh = false;  // c's lanes that inserted their id
+            float dist = 0.0f;
+            // Request, claims and chain under ONE exec mask -- the lanes whose look said "absent"; the
+            // claiming lanes are among them.  (Row registers defined under one mask and consumed under
+            // another are live across the join for the allocator: it parked 68 of them in AGPRs, the chain
+            // paid a v_accvgpr_read per element and the kernel fell to one wave per SIMD.)  A lane of c
+            // that turns out not to be fresh -- its id sat in a later bucket -- evaluates a distance for
+            // nothing.
+            if (want_pre) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(a.rows + (size_t)nb * DS);
+                uint4 w[DS / 4];
+#pragma unroll
+                for (int p = 0; p < DS / 4; p++) w[p] = src[p];
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t old = vis.claim(nb, vb, ct);
+                fresh = old == HX_EMPTY_SLOT;
+                const bool pend = (ct != 4u) & !fresh;
+                if (__ballot(pend)) {
+                    fresh = vis.finish(nb, vb, ct, pend, fresh);
 #ifdef HX_STAMPS
-                dbg_acc[11]++;
+                    dbg_acc[11]++;
 #endif
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float s = chain_sum<DS>(w, qv);
+                dist = __builtin_sqrtf(s);
             }
             const bool want = upper ? want_pre : fresh;
             const u64 vmask = __ballot(valid), fmask = __ballot(fresh);
@@ -632,21 +637,13 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
                 status = HNSW_ERR_OVERFLOW;
                 break;
             }
+            const bool nan = want && dist != dist;
             u64 key = LK_INVALID;
-            bool nan = false;
+            if (want && !nan) key = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | nb;
             STAMP(f2);
             STAMP_ADD(1, f1, f2);
-#ifdef HX_STAMPS
-            unsigned long long t_landed = f2;
-#endif
-            if (__ballot(want)) {
-                const float dist = row_chain<DS>(w, want, qv);
-                nan = want && dist != dist;
-                if (want && !nan) key = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | nb;
-            }
             STAMP(f3);
-            STAMP_ADD(2, f2, t_landed);
-            STAMP_ADD(3, t_landed, f3);
+            STAMP_ADD(3, f2, f3);
 #ifdef HX_STAMPS
             {
                 const uint32_t mm = (uint32_t)__popcll(__ballot(!upper && key < lst.last_key));
