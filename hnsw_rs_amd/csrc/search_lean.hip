@@ -37,6 +37,12 @@
 namespace hx {
 namespace {
 
+// block placement hints for the f32 kernel's pass (a taken branch costs a lone wave ~30 cycles of
+// instruction refetch: SQ_WAIT_INST_ANY was 12 % of the wave's time); measured + 2 % there, nothing for
+// the quant8 kernel, whose loop is left as the compiler lays it out
+#define HX_LIKELY(x) __builtin_expect(!!(x), 1)
+#define HX_UNLIKELY(x) __builtin_expect(!!(x), 0)
+
 constexpr u64 LK_INVALID = ~0ull;
 constexpr u64 LK_MASK = 0x7FFFFFFFFFFFFFFFull;
 constexpr u64 LK_EXPANDED = 1ull << 63;
@@ -459,7 +465,7 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
                 const bool valid = (int32_t)nb >= 0;
                 if (first) {
                     const u64 pm = __ballot((int32_t)nb < 0 && nb != HX_EMPTY_SLOT);
-                    if (pm) {
+                    if (HX_UNLIKELY(pm != 0)) {
                         const uint32_t o = rdlane(nb, (uint32_t)__ffsll((long long)pm) - 1) & ~HX_OVF_FLAG;
                         ovf_lo = uni(a.ovf_off[o]);
                         ovf_hi = uni(a.ovf_off[o + 1]);
@@ -468,8 +474,8 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
                 }
                 const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
                 sum_deg += cnt;
-                if (cnt != 0) {
-                    if (n_vis + cnt > vis_limit) {
+                if (HX_LIKELY(cnt != 0)) {
+                    if (HX_UNLIKELY(n_vis + cnt > vis_limit)) {
                         status = HNSW_ERR_OVERFLOW;
                         break;
                     }
@@ -478,12 +484,12 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
                     const uint32_t nf = (uint32_t)__popcll(fm);
                     n_vis += nf;
                     n_dist += nf;
-                    if (fm) {
+                    if (HX_LIKELY(fm != 0)) {
                         uint32_t ubn = HX_EMPTY_SLOT;
                         if (fresh) ubn = a.upper_base[nb];  // in flight together with the vector row
                         const float dist = row_dist<DS>(a.rows, nb, fresh, qv);
                         const bool nan = fresh && dist != dist;
-                        if (__ballot(nan)) {
+                        if (HX_UNLIKELY(__ballot(nan) != 0)) {
                             status = HNSW_ERR_NAN_INPUT;  // Dist::cmp would panic (dist.rs:32)
                             break;
                         }
@@ -511,7 +517,7 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
                         }
                     }
                 }
-                if (ovf_lo >= ovf_hi) break;
+                if (HX_LIKELY(ovf_lo >= ovf_hi)) break;
             }
             if (!improved || status != HNSW_OK) break;
             cur = new_cur;
@@ -551,7 +557,7 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
             uint32_t pid = HX_EMPTY_SLOT;
             uint32_t nb = HX_EMPTY_SLOT;
             const bool ovf_pass = ovf_lo < ovf_hi;
-            if (ovf_pass) {
+            if (HX_UNLIKELY(ovf_pass)) {
                 // ---- more of the last candidate's neighbours: the same pass without a pick and without
                 // a runner-up (one body for both keeps a single set of row registers in the loop) ----
                 if (lane < 32 && ovf_lo + (uint32_t)lane < ovf_hi) nb = a.ovf_nbrs[ovf_lo + (uint32_t)lane];
@@ -561,13 +567,13 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
                 u64 U[R];
                 lst.unexp_masks(U);
                 const int cpos = Lst<R>::take_first(U);
-                if (cpos < 0) break;  // candidates exhausted / only worse ones left (searcher.rs:35,41-44)
+                if (HX_UNLIKELY(cpos < 0)) break;  // candidates exhausted / only worse ones left (searcher.rs:35,41-44)
                 ppos = Lst<R>::take_first(U);
                 const uint32_t cid = lst.id_at((uint32_t)cpos);
                 if (ppos >= 0) pid = lst.id_at((uint32_t)ppos);
                 lst.mark((uint32_t)cpos, lane);
                 n_exp++;
-                if (pre_c == cid && pre_p == pid) {
+                if (HX_LIKELY(pre_c == cid && pre_p == pid)) {
                     nb = pre_nb;  // both rows were requested during the previous pass
                 } else {
                     if (slot < S0 && (!upper || ppos >= 0)) nb = a.adj0[(size_t)(upper ? pid : cid) * S0 + slot];
@@ -614,7 +620,7 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
                 const uint32_t old = vis.claim(nb, vb, ct);
                 fresh = old == HX_EMPTY_SLOT;
                 const bool pend = (ct != 4u) & !fresh;
-                if (__ballot(pend)) {
+                if (HX_UNLIKELY(__ballot(pend) != 0)) {
                     fresh = vis.finish(nb, vb, ct, pend, fresh);
 #ifdef HX_STAMPS
                     dbg_acc[11]++;
@@ -633,7 +639,7 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
             n_vis += nf_c;
             n_dist += nf_c;
             // the table holds at most vis_limit + 64 ids (checked after the inserts: one hand-off less)
-            if (n_vis > vis_limit) {
+            if (HX_UNLIKELY(n_vis > vis_limit)) {
                 status = HNSW_ERR_OVERFLOW;
                 break;
             }
@@ -651,32 +657,32 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
             }
 #endif
             const u64 nanm = __ballot(nan);
-            if (nanm & 0xFFFFFFFFull) {
+            if (HX_UNLIKELY((nanm & 0xFFFFFFFFull) != 0)) {
                 status = HNSW_ERR_NAN_INPUT;  // Dist::cmp would panic (dist.rs:32)
                 break;
             }
             lst.merge(upper ? LK_INVALID : key, ef, perm, lane);
             STAMP(f3b);
             STAMP_ADD(8, f3, f3b);
-            if (pm & 0xFFFFFFFFull) {  // degree > S0: the rest of c's row goes through the next passes (rare)
+            if (HX_UNLIKELY((pm & 0xFFFFFFFFull) != 0)) {  // degree > S0: the rest of c's row goes through the next passes (rare)
                 const uint32_t c_ovf = rdlane(nb, (uint32_t)__ffsll((long long)(pm & 0xFFFFFFFFull)) - 1) & ~HX_OVF_FLAG;
                 ovf_lo = uni(a.ovf_off[c_ovf]);
                 ovf_hi = uni(a.ovf_off[c_ovf + 1]);
                 if (ovf_lo < ovf_hi) continue;  // (the runner-up is picked again afterwards)
             }
             // ---- is p the next candidate?  then commit it from the registers ----
-            if (!spec_ok) continue;
+            if (HX_UNLIKELY(!spec_ok)) continue;
             u64 V[R];
             lst.unexp_masks(V);
             const int npos = Lst<R>::take_first(V);
-            if (npos < 0) break;
-            if (lst.id_at((uint32_t)npos) != pid) continue;
+            if (HX_UNLIKELY(npos < 0)) break;
+            if (HX_UNLIKELY(lst.id_at((uint32_t)npos) != pid)) continue;
             // The pass after this one will most likely expand the two entries that follow p (measured:
             // three times out of four when p is committed).  Their adjacency rows are requested now and
             // land while p is being committed; if the next pick is a different pair they are dropped.
             {
                 const int apos = Lst<R>::take_first(V);
-                if (apos >= 0) {
+                if (HX_LIKELY(apos >= 0)) {
                     const int bpos = Lst<R>::take_first(V);
                     pre_c = lst.id_at((uint32_t)apos);
                     pre_p = bpos >= 0 ? lst.id_at((uint32_t)bpos) : HX_EMPTY_SLOT;
@@ -696,16 +702,16 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
             const uint32_t pold = vis.claim(nb, vb, pt);
             bool pfresh = pold == HX_EMPTY_SLOT;
             const bool ppend = (pt == 5u) | ((pt < 4u) & !pfresh & (pold != nb));
-            if (__ballot(ppend)) pfresh = vis.finish(nb, vb, pt == 5u ? 5u : 0u, ppend, pfresh);
+            if (HX_UNLIKELY(__ballot(ppend) != 0)) pfresh = vis.finish(nb, vb, pt == 5u ? 5u : 0u, ppend, pfresh);
             const uint32_t nf_p = (uint32_t)__popcll(__ballot(pfresh));
             sum_deg += cnt_p;
             n_vis += nf_p;
             n_dist += nf_p;
-            if (n_vis > vis_limit) {
+            if (HX_UNLIKELY(n_vis > vis_limit)) {
                 status = HNSW_ERR_OVERFLOW;
                 break;
             }
-            if (__ballot(pfresh && nan)) {
+            if (HX_UNLIKELY(__ballot(pfresh && nan) != 0)) {
                 status = HNSW_ERR_NAN_INPUT;
                 break;
             }
@@ -877,7 +883,7 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
                 if (c0 < a.S1) {
                     if (c0 + cslot < a.S1) nb = row[c0 + cslot];
                     const u64 pm = __ballot((int32_t)nb < -1);
-                    if (pm) {
+                    if (HX_UNLIKELY(pm != 0)) {
                         const uint32_t o = rdlane(nb, (uint32_t)__ffsll((long long)pm) - 1) & ~HX_OVF_FLAG;
                         ovf_lo = uni(a.ovf_off[o]);
                         ovf_hi = uni(a.ovf_off[o + 1]);
@@ -998,7 +1004,7 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
             sum_deg += (uint32_t)__popcll(vmask);
             n_vis += nf;
             n_dist += nf;
-            if (n_vis > vis_limit) {  // the table holds at most vis_limit + 32 ids
+            if (HX_UNLIKELY(n_vis > vis_limit)) {  // the table holds at most vis_limit + 32 ids
                 status = HNSW_ERR_OVERFLOW;
                 break;
             }
