@@ -432,6 +432,9 @@ __device__ __forceinline__ float f32_row_sum(const uint4 (&w)[P], const float *y
 // of CH 16-byte pieces each.  The stage loop has a compile-time trip count and is fully unrolled, so
 // the code is straight-line: the loads of stage s + 1 are in flight while stage s is summed and the
 // compiler's s_waitcnt counts are exact (a rolled loop drains them at its header).
+#ifndef HX_WIDE_CH
+#define HX_WIDE_CH 16  // 16-byte pieces per stage buffer of the wide-row loop (two buffers in flight per lane)
+#endif
 template <int DS, int CH, bool ROLLED>
 __device__ __forceinline__ float f32_row_sum_staged(const uint4 *src, const float *yq) {
     constexpr int NP = (DS + 3) / 4, NST = (NP + CH - 1) / CH;
@@ -822,7 +825,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
             if (active) {
                 const uint4 *src = reinterpret_cast<const uint4 *>(v.rows + (size_t)id * v.row_stride);
                 if constexpr (P > 48) {
-                    sm = f32_row_sum_staged<(DS > 0 ? DS : 1), 16, true>(src, yq);
+                    sm = f32_row_sum_staged<(DS > 0 ? DS : 1), HX_WIDE_CH, true>(src, yq);
                 } else {
                     uint4 w[P > 0 ? P : 1];
 #pragma unroll

@@ -40,3 +40,14 @@ for ef in (64, 128, 256):
     bq = s[:, 0].mean() * row_bytes + s[:, 1].mean() * 4 + s[:, 2].mean() * 4 + 4 * d + 8 * n
     print('N=%d d=%d kind=%d recipe=%d ef=%d recall@10 %.4f  %.3f ms/batch  %.2f M q/s  n_dist %.0f n_exp %.1f  alg %.0f GB/s' % (
         N, d, kind, recipe, ef, rec, ms, B / ms / 1e3, s[:, 0].mean(), s[:, 1].mean(), bq * B / ms / 1e6), flush=True)
+    # one launch of all 8192 queries: the machine-filling regime
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    idx.search_batch_device(dQ.data_ptr(), 8 * B, n, ef, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), st.data_ptr(), 0)
+    torch.cuda.synchronize()
+    e0.record()
+    idx.search_batch_device(dQ.data_ptr(), 8 * B, n, ef, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), st.data_ptr(), 0)
+    e1.record(); torch.cuda.synchronize(); ms8 = e0.elapsed_time(e1)
+    sa = st.cpu().numpy()
+    bq8 = sa[:, 0].mean() * row_bytes + sa[:, 1].mean() * 4 + sa[:, 2].mean() * 4 + 4 * d + 8 * n
+    print('    one launch of %d queries: %.3f ms  %.2f M q/s  alg %.0f GB/s; per query n_dist mean %.0f p99 %.0f max %d' % (
+        8 * B, ms8, 8 * B / ms8 / 1e3, bq8 * 8 * B / ms8 / 1e6, sa[:, 0].mean(), np.percentile(sa[:, 0], 99), sa[:, 0].max()), flush=True)
