@@ -163,3 +163,38 @@ def test_mfma_scan_rejects_what_it_does_not_serve():
     q8 = H.HNSW.new(8, 16, 100).insert_bulk(H.synth_rows(0, 1, 0, 300, 100), 1, False)
     with pytest.raises(H.HnswError):
         q8.brute_force_fast(H.synth_rows(0, 2, 0, 4, 100), 10)
+
+
+@pytest.mark.parametrize("kind", [H.VEC_F32, H.VEC_QUANT8])
+def test_lean_kernels_with_rows_longer_than_the_stride(kind):
+    """d = 100 runs the lean kernels (search_lean.hip).  Nodes whose degree exceeds the 32-slot stride keep
+    the rest of their row in the overflow CSR: the f32 kernel sends those rows through its pass body again
+    (no runner-up in such a pass), the quant8 kernel walks them in place; a hub may also be the runner-up,
+    which is then not speculated on (searcher.rs:45-71 sees one neighbour list either way)."""
+    from tests.util import product_from_oracle, rand_vectors
+    n, d, m = 3000, 100, 4  # layer-0 cap 8, stride 32
+    vs, qs = rand_vectors(n, d, 31), rand_vectors(96, d, 32)
+    lv = O.draw_levels(n, m, 5)
+    orc = O.OracleHNSW(m, None, d, kind).insert_bulk(vs, lv)
+    ids, offs, nbrs = orc.layer_csr(0)
+    adj = {int(i): set(int(x) for x in nbrs[int(offs[k]):int(offs[k + 1])]) for k, i in enumerate(ids)}
+    hubs = ((5, 70), (9, 40), (11, 33), (700, 150))
+    for hub, cnt in hubs:
+        for t in range(100, 100 + cnt):
+            adj[hub].add(t)
+            adj[t].add(hub)
+    rows = [sorted(adj[int(i)]) for i in ids]
+    orc2 = O.OracleHNSW(m, None, d, kind)
+    orc2.import_points(vs, lv)
+    orc2.import_layer(0, ids, np.cumsum([0] + [len(r) for r in rows]).astype(np.uint64),
+                      np.concatenate([np.array(r, dtype=np.uint32) for r in rows]))
+    for l in range(1, orc.nb_layers):
+        orc2.import_layer(l, *orc.layer_csr(l))
+    orc2.set_ep(orc.ep)
+    index = product_from_oracle(orc2, vs, lv)
+    assert index.get_layer(0).degree(700) > 128
+    for i, (hub, _) in enumerate(hubs):  # queries that certainly expand the hubs
+        qs[i] = vs[hub]
+    for ef in (1, 10, 64, 68, 128):
+        assert_search_equal(index.search_batch(qs, 10, ef), orc2.search_batch(qs, 10, ef),
+                            "lean overflow kind=%d ef=%d" % (kind, ef))
