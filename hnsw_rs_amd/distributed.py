@@ -193,6 +193,15 @@ class PipelinedShardedSearch:
         self.ev_q = [self.lanes.event() for _ in range(depth)]
         self.ev_r = [self.lanes.event() for _ in range(depth)]
         self.ev_g = [self.lanes.event() for _ in range(depth)]
+        # the root reads the failed-query words through a pinned host buffer filled on the communication lane:
+        # a plain .cpu() would wait for the COMPUTE lane, i.e. stall the host behind the searches of the
+        # group it has just enqueued (measured: 16 us per step at one rank)
+        self.ev_c = [self.lanes.event() for _ in range(depth)]
+        self.bad_host = None
+        if self.rank == root:
+            self.bad_host = [torch.zeros(W, dtype=torch.int32) for _ in range(depth)]
+            if torch.device(device).type == "cuda":
+                self.bad_host = [t.pin_memory() for t in self.bad_host]
         self.pending = None  # (group index, steps) whose gather has not been enqueued yet
         self.gathered = []   # groups gathered but not yet checked: (group index, steps)
         self.n_groups = 0
@@ -240,6 +249,8 @@ class PipelinedShardedSearch:
             src = self.res[b]
             if self.rank == self.root:
                 dist.gather(src, list(self.out[b].unbind(0)), dst=self.root, group=self.group)
+                self.bad_host[b].copy_(self.out[b][:, self.G].reshape(self.world, -1)[:, 0], non_blocking=True)
+                L.record(L.comm, self.ev_c[b])
             else:
                 dist.gather(src, None, dst=self.root, group=self.group)
             L.record(L.comm, self.ev_g[b])
@@ -251,9 +262,9 @@ class PipelinedShardedSearch:
             k, g = self.gathered.pop(0)
             if self.rank != self.root:
                 continue
-            if self.ev_g[k % self.depth] is not None:
-                self.ev_g[k % self.depth].synchronize()
-            bad = self.out[k % self.depth][:, self.G].reshape(self.world, -1)[:, 0].cpu()
+            if self.ev_c[k % self.depth] is not None:
+                self.ev_c[k % self.depth].synchronize()  # the word has landed; nothing else is waited for
+            bad = self.bad_host[k % self.depth].clone()
             if int(bad.sum()) != 0:
                 raise RuntimeError("group %d: %s queries per rank did not finish with status 0 (visited table "
                                    "overflow or NaN); re-run them through hnsw_search_batch" % (k, bad.tolist()))
