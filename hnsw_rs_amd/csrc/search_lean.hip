@@ -963,7 +963,9 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
         // One candidate per pass.  (Evaluating the runner-up as well -- its rows fetched together with
         // c's, its chain run when it is committed -- was built, parity-tested and measured slower:
         // 0.196 against 0.180 ms per batch at efSearch 68.  So was requesting the rows right after the
-        // look, before the claim, which pays for the f32 rows' 25 loads: 0.186 against 0.180 ms here.)
+        // look, before the claim, which pays for the f32 rows' 25 loads: 0.186 against 0.180 ms here, and
+        // still 0.1788 against 0.1765 ms with request, claim and chain under one exec mask.  So was the
+        // f32 kernel's two-candidate pass with the wanted rows packed onto the pairs: + 6 to + 10 %.)
         while (true) {
             u64 U[R];
             lst.unexp_masks(U);
