@@ -792,6 +792,10 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
 
     uint32_t n_dist = 0, n_exp = 0, sum_deg = 0, n_vis = 0;
     int32_t status = HNSW_OK;
+#ifdef HX_STAMPS
+    unsigned long long dbg_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
 
     // ---- the query goes through the same quantiser as a stored vector (Point::new -> QuantVec::new,
     // template.rs:313, quant.rs:41-66) and is kept dequantised, in this lane's half order, in registers ----
@@ -944,6 +948,9 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
     }
 
     // ---- layer 0 with ef (template.rs:326) ----
+#ifdef HX_STAMPS
+    dbg_acc[7] = __builtin_readcyclecounter() - t_begin;
+#endif
     const uint32_t ef = max(1u, a.ef);
     Lst<R> lst;
     lst.init();
@@ -967,6 +974,7 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
         // still 0.1788 against 0.1765 ms with request, claim and chain under one exec mask.  So was the
         // f32 kernel's two-candidate pass with the wanted rows packed onto the pairs: + 6 to + 10 %.)
         while (true) {
+            STAMP(f0);
             u64 U[R];
             lst.unexp_masks(U);
             const int cpos = Lst<R>::take_first(U);
@@ -991,6 +999,11 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
                 if (cslot < S0) pre_nb = a.adj0[(size_t)pre_c * S0 + cslot];
             }
             const u64 pm = __ballot((int32_t)nb < -1);  // 0x80000000 | overflow row (degree > S0, rare)
+#ifdef HX_STAMPS
+            dbg_acc[6]++;
+#endif
+            STAMP(f1);
+            STAMP_ADD(0, f0, f1);
             const bool valid = (int32_t)nb >= 0;
             // ---- visited: the pair looks at the id's home bucket, the even lane claims a slot ----
             const uint32_t vb = vis.home(nb);
@@ -1010,6 +1023,8 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
                 status = HNSW_ERR_OVERFLOW;
                 break;
             }
+            STAMP(f2);
+            STAMP_ADD(1, f1, f2);
             u64 key = LK_INVALID;
             if (fmask) {
                 const float dist = eval(nb, fresh);
@@ -1020,7 +1035,11 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
                 }
                 if (mine) key = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | nb;
             }
+            STAMP(f3);
+            STAMP_ADD(3, f2, f3);
             lst.merge(key, ef, perm, lane);
+            STAMP(f4);
+            STAMP_ADD(8, f3, f4);
             if (pm) {  // degree > S0: the rest of the row
                 const uint32_t c_ovf = rdlane(nb, (uint32_t)__ffsll((long long)pm) - 1) & ~HX_OVF_FLAG;
                 const uint32_t lo = uni(a.ovf_off[c_ovf]), hi = uni(a.ovf_off[c_ovf + 1]);
@@ -1070,6 +1089,12 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
         a.out_ids[(size_t)q * a.n + idx] = HX_EMPTY_SLOT;
         if (a.out_dists) a.out_dists[(size_t)q * a.n + idx] = __builtin_inff();
     }
+#ifdef HX_STAMPS
+    if (lane == 0 && a.dbg) {
+        dbg_acc[4] = __builtin_readcyclecounter() - t_begin;
+        for (int i = 0; i < 16; i++) a.dbg[(size_t)q * 16 + i] = dbg_acc[i];
+    }
+#endif
     if (lane == 0) {
         if (a.out_counts) a.out_counts[q] = count;
         hnsw_query_stats st;
