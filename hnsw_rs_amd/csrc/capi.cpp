@@ -104,8 +104,8 @@ int check_search_args(const hnsw_index *h, uint32_t ef) {
         set_error("index is empty");
         return HNSW_ERR_EMPTY;
     }
-    if (ef > 64 * 8) {
-        set_error("ef = %u is above the supported maximum of 512", ef);
+    if (ef > 64 * 16) {
+        set_error("ef = %u is above the supported maximum of 1024", ef);
         return HNSW_ERR_ARG;
     }
     return HNSW_OK;

@@ -45,7 +45,8 @@ static constexpr u64 KEY_INVALID = ~0ull;
 static constexpr u64 KEY_MASK = 0x7FFFFFFFFFFFFFFFull;  // drops the expanded flag
 static constexpr u64 KEY_EXPANDED = 1ull << 63;
 
-#define HX_MAX_R 8  // ef <= 64 * HX_MAX_R
+#define HX_MAX_R 8  // ef <= 64 * HX_MAX_R on the specialised kernels and in the on-device build
+#define HX_MAX_R_WIDE 16  // ef <= 1024 on the any-dimension search kernel
 
 // Diagnostic build only (make stamps): per-phase cycle shares of the inline-rows expansion loop,
 // written to a side buffer nothing else reads.  The shipped library is built without HX_STAMPS.
@@ -2606,6 +2607,18 @@ int launch_search(const DevView &v, const SearchArgs &a_in, uint32_t nblocks, ui
     if (a.entries) ef_max = std::max(ef_max, a.n_entry);
     if (slots_log2 == 0) slots_log2 = default_slots_log2(ef_max, v.S0);
     if (lean_applicable(v, a, ef_max)) return launch_lean(v, a, nblocks, slots_log2, stream);
+    if (ef_max > 64 * HX_MAX_R) {
+        // beyond 512 entries: the any-dimension kernel with sixteen list registers per lane (ef <= 1024;
+        // one wave per CU: the visited table takes 128 KiB).  The reference has no limit
+        // (template.rs:306-311); this is as far as a wave-resident list goes.
+        if (ef_max > 64 * HX_MAX_R_WIDE) {
+            set_error("ef = %u is above the supported maximum of %d", ef_max, 64 * HX_MAX_R_WIDE);
+            return HNSW_ERR_ARG;
+        }
+        if (v.kind == HNSW_VEC_QUANT8)
+            return launch_one<HNSW_VEC_QUANT8, 0, 0, HX_MAX_R_WIDE, false>(v, a, nblocks, slots_log2, stream);
+        return launch_one<HNSW_VEC_F32, 0, 0, HX_MAX_R_WIDE, false>(v, a, nblocks, slots_log2, stream);
+    }
     if (v.kind == HNSW_VEC_QUANT8) {
         const uint32_t P = v.half_bytes / 16;
         if (v.dim == 100) return launch_r<HNSW_VEC_QUANT8, 4, 100>(v, a, nblocks, slots_log2, stream, ef_max);

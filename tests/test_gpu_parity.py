@@ -96,14 +96,27 @@ def test_dimensions_and_vector_kinds(kind, d):
 
 
 @pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
-@pytest.mark.parametrize("ef", [65, 128, 200, 300, 512])
+@pytest.mark.parametrize("ef", [65, 128, 200, 300, 512, 513, 700, 1024])
 def test_large_ef_uses_wider_lists(ef, kind):
+    """two, four, eight list registers per lane; beyond 512 the any-dimension kernel with sixteen (ef <= 1024);
+    above that an error (the reference has no limit, template.rs:306-311: a documented limit here)"""
     n, d, m = 3000, 24, 16
     vs, qs = rand_vectors(n, d, 1), rand_vectors(32, d, 2)
     index, orc = both(vs, O.draw_levels(n, m, 9), m, kind=kind, threads=4)
     assert_search_equal(index.search_batch(qs, 100, ef), orc.search_batch(qs, 100, ef), "ef=%d" % ef)
     with pytest.raises(H.HnswError):
-        index.search_batch(qs, 10, 513)
+        index.search_batch(qs, 10, 1025)
+
+
+@pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
+def test_ef_above_512_at_the_specialised_dimensions(kind):
+    """d = 100 normally runs the lean / specialised kernels; ef 600 and 1000 route it through the
+    any-dimension kernel, n = 600 results per query"""
+    n, d, m = 4000, 100, 16
+    vs, qs = rand_vectors(n, d, 5), rand_vectors(16, d, 6)
+    index, orc = both(vs, O.draw_levels(n, m, 11), m, kind=kind, threads=4)
+    for ef in (600, 1000):
+        assert_search_equal(index.search_batch(qs, 600, ef), orc.search_batch(qs, 600, ef), "ef=%d" % ef)
 
 
 @pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
