@@ -19,7 +19,7 @@
         }                                                                        \
     } while (0)
 
-template <int ROW>
+template <int ROW, bool NT>
 __global__ void __launch_bounds__(64) k_gather(const uint8_t *tab, uint64_t nrows, uint32_t iters, uint32_t *sink) {
     constexpr int P = ROW / 16;
     const uint32_t gid = blockIdx.x * 64 + threadIdx.x;
@@ -33,30 +33,38 @@ __global__ void __launch_bounds__(64) k_gather(const uint8_t *tab, uint64_t nrow
         const uint4 *src = reinterpret_cast<const uint4 *>(tab + row * ROW);
         uint4 w[P];
 #pragma unroll
-        for (int p = 0; p < P; p++) w[p] = src[p];
+        for (int p = 0; p < P; p++) {
+            if (NT) {  // non-temporal: the row is not going to be read again
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + p));
+                w[p] = make_uint4(t.x, t.y, t.z, t.w);
+            } else {
+                w[p] = src[p];
+            }
+        }
 #pragma unroll
         for (int p = 0; p < P; p++) acc += w[p].x ^ w[p].y ^ w[p].z ^ w[p].w;
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
-template <int ROW>
+template <int ROW, bool NT>
 static void run(const uint8_t *tab, uint64_t bytes, uint32_t waves, uint32_t *sink) {
     const uint64_t nrows = bytes / ROW;
     const uint32_t iters = 64;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k_gather<ROW>, dim3(waves), dim3(64), 0, 0, tab, nrows, 8u, sink);
+    hipLaunchKernelGGL((k_gather<ROW, NT>), dim3(waves), dim3(64), 0, 0, tab, nrows, 8u, sink);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k_gather<ROW>, dim3(waves), dim3(64), 0, 0, tab, nrows, iters, sink);
+    hipLaunchKernelGGL((k_gather<ROW, NT>), dim3(waves), dim3(64), 0, 0, tab, nrows, iters, sink);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double gb = (double)waves * 64 * iters * ROW / 1e9;
-    printf("table %7.2f GB, rows of %4d B, %5u waves: %8.3f ms  %7.0f GB/s\n", bytes / 1e9, ROW, waves, ms, gb / (ms / 1e3));
+    printf("table %7.2f GB, rows of %4d B, %5u waves%s: %8.3f ms  %7.0f GB/s\n", bytes / 1e9, ROW, waves, NT ? ", non-temporal loads" : "", ms, gb / (ms / 1e3));
     fflush(stdout);
 }
 
@@ -72,8 +80,10 @@ int main(int argc, char **argv) {
         CK(hipMemset(tab, 1, bytes));
         CK(hipDeviceSynchronize());
         for (uint32_t waves : {1024u, 8192u}) {
-            run<512>(tab, bytes, waves, sink);
-            run<3072>(tab, bytes, waves, sink);
+            run<512, false>(tab, bytes, waves, sink);
+            run<512, true>(tab, bytes, waves, sink);
+            run<3072, false>(tab, bytes, waves, sink);
+            run<3072, true>(tab, bytes, waves, sink);
         }
         CK(hipFree(tab));
     }
