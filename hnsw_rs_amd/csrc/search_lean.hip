@@ -21,7 +21,11 @@
 //     or met a full bucket;
 //   - the list is interleaved (entry i = lane i / R, register i % R), so an insertion is a one-lane DPP
 //     shift without a carry between registers; one or two survivors are shift-inserted, larger batches
-//     take the rank + LDS scatter;
+//     go through LDS without a vector -> scalar hand-off per survivor (list entries count their shift,
+//     survivors their rank, the holes the scattered list leaves take the survivors in order);
+//   - the row request, the visited claims and the distance chain of a pass sit under ONE exec mask
+//     (split over several, the allocator parked the row registers in AGPRs: one wave per SIMD and a
+//     v_accvgpr_read per element), and the pass's uniform branches carry likely / unlikely hints;
 //   - the upper layers (ef = 1, searcher.rs:23-103 degenerates to a greedy walk) keep just the best
 //     key, and the next node's adjacency base (upper_base) is fetched together with the vector rows of
 //     the neighbours, so an expansion is two dependent round trips instead of three.
