@@ -261,22 +261,25 @@ def choose_ef(c, index, kind_name):
 
 
 def time_local(c, local_search, steps, warmup):
-    """K back-to-back launches on the current stream, one HIP event pair per launch"""
+    """The timed region: K back-to-back launches on the current stream between two synchronisations, with one
+    HIP event pair around all of them.  Returns (wall seconds, GPU ms per launch = event time / K).
+    No events between the launches: a pair per launch costs ~7 us per step and reads 2 us long
+    (scripts/timing_probe.py; rocprofv3's kernel durations agree with the figure returned here)."""
     torch = c.torch
     B, nqb = c.args.batch, c.args.query_batches
     qs = [c.dQ[b][:B].contiguous() for b in range(nqb)]
     for i in range(warmup):
         local_search(qs[i % nqb])
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    r0.record()
     for i in range(steps):
-        ev[i][0].record()
         local_search(qs[(warmup + i) % nqb])
-        ev[i][1].record()
+    r1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    return elapsed, float(np.mean([x.elapsed_time(y) for x, y in ev]))
+    return elapsed, r0.elapsed_time(r1) / steps
 
 
 def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
@@ -324,6 +327,7 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
                    if d == 100 and ef <= 128 and os.environ.get("HNSW_MI355X_LEAN") != "0" and
                    (kind == H.VEC_F32 or os.environ.get("HNSW_MI355X_LEAN_Q8") != "0") else "hx_search_kernel"),
         "kernel_ms": round(kern_ms, 5),
+        "kernel_ms_note": "average launch duration: one HIP event pair around the K launches of the timed region, / K",
         "algorithmic_bytes_per_launch": round(bytes_per_launch),
         "per_query": {"n_dist": round(float(st[:, 0].mean()), 2), "n_exp": round(float(st[:, 1].mean()), 2),
                       "sum_deg": round(float(st[:, 2].mean()), 2), "bytes": round(float(bq.mean()), 1),
@@ -335,9 +339,9 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
     if ef != 64:  # the configured efSearch = 64 timed too when the metric's recall needed a larger ef
         from hnsw_rs_amd.distributed import make_device_search
         ls64 = make_device_search(index, n, 64, B, c.dev)
-        _, ms64 = time_local(c, ls64, 50, 5)
-        out["at_configured_efSearch_64"] = {"queries_per_s_per_gpu": round(B / ms64 * 1e3, 1),
-                                            "ms_per_step": round(ms64, 5),
+        el64, ms64 = time_local(c, ls64, 50, 5)
+        out["at_configured_efSearch_64"] = {"queries_per_s_per_gpu": round(50 * B / el64, 1),
+                                            "ms_per_step": round(el64 / 50 * 1e3, 5), "kernel_ms": round(ms64, 5),
                                             "recall_at_%d" % n: recall_by_ef[64]}
     # Not the metric: the same 1024-query launches with several batches in flight (one stream each).
     # A 1024-query launch puts one wave on every SIMD; independent batches share the SIMDs and hide each

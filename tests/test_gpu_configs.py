@@ -198,3 +198,19 @@ def test_lean_kernels_with_rows_longer_than_the_stride(kind):
     for ef in (1, 10, 64, 68, 128):
         assert_search_equal(index.search_batch(qs, 10, ef), orc2.search_batch(qs, 10, ef),
                             "lean overflow kind=%d ef=%d" % (kind, ef))
+
+
+@pytest.mark.parametrize("kind", [H.VEC_F32, H.VEC_QUANT8])
+def test_one_large_launch_answers_like_many_small_ones(kind):
+    """4096 queries in ONE launch (four waves per SIMD resident together, two per SIMD at a time for the f32
+    kernel) against the oracle: occupancy must not change a result (each query owns its wave and its LDS)"""
+    n, d, m = 24000, 100, 16
+    vs = H.synth_rows(0, 0x5EED0001, 0, n, d)
+    qs = H.synth_rows(0, 0x5EED0002, 0, 4096, d)
+    lv = O.draw_levels(n, m, 0x5EED0003)
+    idx = H.HNSW.new(m, 32, d, kind)
+    idx.insert_bulk_device(vs, 8, False, levels=lv)
+    orc = oracle_from_product(idx, vs, lv)
+    for ef in (64, 68):
+        assert_search_equal(idx.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=8),
+                            "one launch of 4096, kind=%d ef=%d" % (kind, ef))
