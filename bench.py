@@ -76,6 +76,12 @@ def parse():
     p.add_argument("--recipe", type=int, default=0, help="0 = A (low intrinsic dim), 1 = B (isotropic)")
     p.add_argument("--query-batches", type=int, default=10, help="distinct batches cycled through")
     p.add_argument("--build-threads", type=int, default=0)
+    p.add_argument("--build-batch", default="8192:8",
+                   help="insert batches of the on-device build as MAX:DIV (min(MAX, connected / DIV) points at a "
+                        "time; the library default).  Smaller batches stand closer to the reference's one-at-a-time "
+                        "insertion: 256:64 lifts recall@10 by 0.0006 at efSearch 64 and 68 for 0.3 s more per 1M "
+                        "points (scripts/build_schedule_recall.py) -- which puts f32 at 0.99008 at efSearch 64, i.e. "
+                        "ON the metric's line (standard error 0.0003); the default keeps the headline clear of it")
     p.add_argument("--cpu-build", action="store_true",
                    help="build the index with the host threads only (default: on-device build, "
                         "hnsw_insert_bulk_device)")
@@ -165,7 +171,11 @@ def get_index(c, kind_name):
     import hnsw_rs_amd as H
     a = c.args
     kind = H.VEC_QUANT8 if kind_name == "quant8" else H.VEC_F32
-    tag = "n%d_d%d_m%d_efc%d_%s_r%d%s" % (a.n_points, a.dim, a.m, a.ef_cons, kind_name, a.recipe, "_unit" if a.unit_rows else "")
+    bb = a.build_batch
+    bmax, bdiv = (int(x) for x in bb.split(":"))
+    c.build_batch = bb
+    tag = "n%d_d%d_m%d_efc%d_%s_r%d%s%s" % (a.n_points, a.dim, a.m, a.ef_cons, kind_name, a.recipe,
+                                           "_unit" if a.unit_rows else "", "" if bb == "8192:8" else "_b%d-%d" % (bmax, bdiv))
     cache_dir = os.path.join(a.index_cache, tag)
     index = None
     t0 = time.time()
@@ -181,6 +191,8 @@ def get_index(c, kind_name):
             t1 = time.time()
             index = H.HNSW.new(a.m, a.ef_cons, a.dim, kind)
             index.set_device(c.local_rank)
+            index.set_option("gpu_build_batch_max", bmax)
+            index.set_option("gpu_build_batch_div", bdiv)
             # rows are generated and handed over in slabs (HNSW::insert_bulk may be called repeatedly,
             # template.rs:493-504): the host never holds more than one slab beside the index itself
             slab = a.n_points
@@ -599,7 +611,8 @@ def main():
                                        " on unit-normalised rows (cosine order = L2 order; the reference has no cosine metric)"
                                        if args.unit_rows else "", m, ef, B, kind_note[args.kind], "AB"[args.recipe]),
                        "n_points": N, "dim": d, "M": m, "ef_construction": args.ef_cons, "efSearch": ef,
-                       "n": n, "batch_per_gpu": B, "vec_kind": args.kind,
+                       "n": n, "batch_per_gpu": B, "vec_kind": args.kind, "index_tag": tag,
+                       "build_batch": getattr(c, "build_batch", None),
                        "parallelism": "replicated index, query batch sharded over %d GPU(s)" % world},
         }
         out.update(result)

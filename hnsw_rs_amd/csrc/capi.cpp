@@ -41,6 +41,12 @@ struct hnsw_index {
     hx::DeviceIndex dev;
     int device = -1;
     int gpu_build = 0;  // option "gpu_build": insert_bulk runs the on-device build (1 host connect, 2 device connect)
+    // The on-device build inserts its points in batches of min(build_batch_max, max(64, connected /
+    // build_batch_div)): the points of a batch do not see one another.  The defaults
+    // build 1M points in 0.7 s; smaller batches stand closer to the reference's one-at-a-time insertion
+    // (options "gpu_build_batch_max", "gpu_build_batch_div": 256 and 64 take 4 s per 1M points and lift
+    // recall@10 at efSearch 64 from 0.9894 to 0.9901 on the bench's index).
+    uint32_t build_batch_max = 8192, build_batch_div = 8;
     // set when an on-device build stopped half way (HIP error, failed exchange): the new points are stored
     // but not all of them are connected, so every later search or build on this handle fails loudly
     // instead of answering from an incomplete graph
@@ -339,7 +345,7 @@ int gpu_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_th
 
     while (pos < order.size()) {
         const size_t B = std::min<size_t>(order.size() - pos,
-                                          std::min<uint64_t>(BMAX, std::max<uint64_t>(64, connected / 8)));
+                                          std::min<uint64_t>(std::min<uint64_t>(BMAX, h->build_batch_max), std::max<uint64_t>(64, connected / h->build_batch_div)));
         const NodeID *batch = &order[pos];
         auto t0 = std::chrono::steady_clock::now();
         HIP_TRY(hipMemcpy(dIds.p, batch, B * 4, hipMemcpyHostToDevice));
@@ -617,7 +623,7 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     if (!sh) {
         uint64_t c = n_before + pos;
         for (size_t q = pos; q < order.size();) {
-            const size_t Bq = std::min<size_t>(order.size() - q, std::min<uint64_t>(BMAX, std::max<uint64_t>(64, c / 8)));
+            const size_t Bq = std::min<size_t>(order.size() - q, std::min<uint64_t>(std::min<uint64_t>(BMAX, h->build_batch_max), std::max<uint64_t>(64, c / h->build_batch_div)));
             uint64_t need = 0;
             for (size_t i = 0; i < Bq; i++) need += ((uint64_t)host.levels[order[q + i]] + 1) * m;
             need_max = std::max(need_max, need);
@@ -657,7 +663,7 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
 
     while (pos < order.size()) {
         const size_t B = std::min<size_t>(order.size() - pos,
-                                          std::min<uint64_t>(BMAX, std::max<uint64_t>(64, connected / 8)));
+                                          std::min<uint64_t>(std::min<uint64_t>(BMAX, h->build_batch_max), std::max<uint64_t>(64, connected / h->build_batch_div)));
         const NodeID *batch = &order[pos];
         auto t0 = std::chrono::steady_clock::now();
         // this rank's slice of the batch (everything when not sharded)
@@ -1436,6 +1442,20 @@ int hnsw_set_option(hnsw_index *h, const char *key, int64_t value) {
         h->dev.fat_budget_bytes = (uint64_t)value << 20;
     } else if (!strcmp(key, "gpu_build")) {
         h->gpu_build = (int)value;
+        return HNSW_OK;
+    } else if (!strcmp(key, "gpu_build_batch_max")) {
+        if (value < 1) {
+            set_error("gpu_build_batch_max must be positive");
+            return HNSW_ERR_ARG;
+        }
+        h->build_batch_max = (uint32_t)std::min<int64_t>(value, 1 << 20);
+        return HNSW_OK;
+    } else if (!strcmp(key, "gpu_build_batch_div")) {
+        if (value < 1) {
+            set_error("gpu_build_batch_div must be positive");
+            return HNSW_ERR_ARG;
+        }
+        h->build_batch_div = (uint32_t)std::min<int64_t>(value, 1 << 20);
         return HNSW_OK;
     } else {
         set_error("unknown option %s", key);

@@ -84,8 +84,8 @@ for kind in ("f32", "quant8"):
               "16-B/lane loads (MI355X_MICROARCH.md, HBM), write %.2f MB; algorithmic %.1f MB; ratio %.2f" % (
                   fetch_kb / 1024, 2 * fetch_kb / 1024, write_kb / 1024, alg / 1e6, hbm / alg))
         a = line["config"]
-        entries.append({"workload": "n%d_d%d_m%d_efc%d_%s_r0" % (a["n_points"], a["dim"], a["M"],
-                                                                 a["ef_construction"], kind),
+        entries.append({"workload": a.get("index_tag") or "n%d_d%d_m%d_efc%d_%s_r0" % (a["n_points"], a["dim"], a["M"],
+                                                                                        a["ef_construction"], kind),
                         "ef": a["efSearch"], "batch": a["batch_per_gpu"], "fetch_size_kb_raw": fetch_kb,
                         "write_size_kb": write_kb, "hbm_bytes_per_launch": hbm})
 import hashlib
