@@ -238,7 +238,11 @@ int hnsw_device_bytes(const hnsw_index *h, uint64_t *bytes);
  *   "inline_budget_mb" largest inline-rows allocation the auto mode accepts (default 65536)
  *   "gpu_build"        0 (default): hnsw_insert_bulk(_levels) is the CPU build; 2: it runs the on-device
  *                      build; 1: on-device searches with connect / prune on host threads (also what
- *                      hnsw_insert_bulk_device does while this is 1) */
+ *                      hnsw_insert_bulk_device does while this is 1)
+ *   "gpu_build_batch_max", "gpu_build_batch_div"
+ *                      the on-device build inserts min(max, connected / div) points at a time (defaults
+ *                      8192 and 8); 256 and 64 stand closer to the reference's one-at-a-time insertion
+ *                      (recall@10 + 0.0006 on the bench's index) for ~0.3 s more per 1M points */
 int hnsw_set_option(hnsw_index *h, const char *key, int64_t value);
 
 /* ---- harness helpers (not part of the reference's API) --------------------------------------- */
