@@ -214,3 +214,27 @@ def test_one_large_launch_answers_like_many_small_ones(kind):
     for ef in (64, 68):
         assert_search_equal(idx.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=8),
                             "one launch of 4096, kind=%d ef=%d" % (kind, ef))
+
+
+def test_device_build_batch_schedule_options():
+    """hnsw_set_option "gpu_build_batch_max" / "gpu_build_batch_div": smaller insert batches (closer to the
+    reference's one-at-a-time insert_bulk, template.rs:493-504) give a different, equally valid graph: every
+    search on it is still the oracle's on that graph, and recall does not drop"""
+    n, d, m = 20000, 100, 16
+    vs = H.synth_rows(0, 0x5EED0001, 0, n, d)
+    qs = H.synth_rows(0, 0x5EED0002, 0, 256, d)
+    lv = O.draw_levels(n, m, 0x5EED0003)
+    recalls = []
+    for bmax, bdiv in ((8192, 8), (64, 64)):
+        idx = H.HNSW.new(m, 32, d, H.VEC_F32)
+        idx.set_option("gpu_build_batch_max", bmax)
+        idx.set_option("gpu_build_batch_div", bdiv)
+        idx.insert_bulk_device(vs, 8, False, levels=lv)
+        orc = oracle_from_product(idx, vs, lv)
+        got = idx.search_batch(qs, 10, 64)
+        assert_search_equal(got, orc.search_batch(qs, 10, 64, nthreads=8), "schedule %d:%d" % (bmax, bdiv))
+        truth, _ = idx.brute_force(qs, 10)
+        recalls.append(sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(got[0], truth)) / 2560.0)
+    assert min(recalls) > 0.98, recalls
+    with pytest.raises(H.HnswError):
+        idx.set_option("gpu_build_batch_max", 0)
