@@ -565,7 +565,10 @@ def main():
         i = first
         while i < first + count:
             g = min(G, first + count - i)
-            qg = torch.stack([c.dQ[(i + j) % nqb] for j in range(g)], 0) if rank == 0 else None
+            qg = None
+            if rank == 0:  # the group's queries are put together on the lane that scatters them
+                with pipe.lanes.on(pipe.lanes.comm):
+                    qg = torch.stack([c.dQ[(i + j) % nqb] for j in range(g)], 0)
             pipe.submit(qg, g)  # scatter / searches / gather of neighbouring groups overlap
             i += g
 

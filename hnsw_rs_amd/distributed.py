@@ -237,7 +237,7 @@ class PipelinedShardedSearch:
                 r = self.res[b][j]
                 self.search_step(self.q[b][j], r[0], r[1], self.stats[b][j], L.compute)
             # failed queries of the group, on the device, next to the results
-            bad = (self.stats[b][:g, :, 3] != 0).sum().to(torch.int32)
+            bad = torch.count_nonzero(self.stats[b][:g, :, 3]).to(torch.int32)
             self.res[b][self.G].view(-1)[0:1].copy_(bad.view(1))
         L.record(L.compute, self.ev_r[b])
 
