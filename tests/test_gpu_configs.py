@@ -238,3 +238,38 @@ def test_device_build_batch_schedule_options():
     assert min(recalls) > 0.98, recalls
     with pytest.raises(H.HnswError):
         idx.set_option("gpu_build_batch_max", 0)
+
+
+@pytest.mark.parametrize("kind", [H.VEC_F32, H.VEC_QUANT8])
+def test_full_size_properties_1m_x_100d(kind):
+    """configs[1] at its full size (1M x 100d, M = 16, efSearch 64 / 68, batches of 1024): the oracle is checked
+    at this size by bench.py's parity leg; here the properties that need no oracle.  (1) a result row is ascending in
+    (distance, id) and holds n distinct ids; (2) every reported distance is bit-for-bit the distance kernel's for that
+    (query, id) -- VecBase::dist2many, vectors/src/lib.rs:17-22; (3) the same batch twice gives the same bits;
+    (4) a query answers the same alone as inside a batch of 1024 (one wave, one LDS block per query); (5) the exact
+    nearest neighbour (exhaustive scan, template.rs:531-541) is in the top 10 for >= 98 % of the queries."""
+    n_pts, d, m, n = 1_000_000, 100, 16, 10
+    vs = H.synth_rows(0, 0x5EED0001, 0, n_pts, d, 16)
+    qs = H.synth_rows(0, 0x5EED0002, 0, 1024, d, 8)
+    idx = H.HNSW.new(m, 32, d, kind)
+    idx.insert_bulk_device(vs, 16, False)
+    assert idx.len() == n_pts
+    for ef in (64, 68):
+        ids, dists, counts, stats = idx.search_batch(qs, n, ef)
+        assert (counts == n).all() and (np.asarray(stats)[:, 3] == 0).all()
+        key = (dists.view(np.uint32).astype(np.uint64) << np.uint64(32)) | ids.astype(np.uint64)
+        assert (np.diff(key.astype(np.int64), axis=1) > 0).all(), "rows ascending in (distance, id), ids distinct"
+        for qi in (0, 17, 511, 1023):
+            again = idx.distance_batch(qs[qi], ids[qi])
+            assert np.array_equal(again.view(np.uint32), dists[qi].view(np.uint32)), "distance bits, query %d" % qi
+        ids2, dists2, _, stats2 = idx.search_batch(qs, n, ef)
+        assert np.array_equal(ids, ids2) and np.array_equal(dists.view(np.uint32), dists2.view(np.uint32))
+        assert np.array_equal(np.asarray(stats), np.asarray(stats2))
+        for qi in (3, 700):
+            a_ids, a_d, _, a_st = idx.search_batch(qs[qi:qi + 1], n, ef)
+            assert np.array_equal(a_ids[0], ids[qi]) and np.array_equal(a_d[0].view(np.uint32), dists[qi].view(np.uint32))
+            assert np.array_equal(np.asarray(a_st)[0, :3], np.asarray(stats)[qi, :3])
+    truth, _ = idx.brute_force(qs[:128], 1)
+    got, _, _, _ = idx.search_batch(qs[:128], n, 68)
+    hit = sum(int(truth[i, 0] in got[i]) for i in range(128))
+    assert hit >= 126, hit
