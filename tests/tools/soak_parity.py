@@ -1,4 +1,5 @@
-"""parity soak on a mid-size index (gpurun): many queries x many efSearch values, both vector kinds,
+"""(test infrastructure: uses the CPU oracle; run from the repo root: python tests/tools/soak_parity.py)
+parity soak on a mid-size index (gpurun): many queries x many efSearch values, both vector kinds,
 ids / distances / counters against the CPU oracle holding the same graph"""
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')

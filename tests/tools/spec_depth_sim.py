@@ -1,4 +1,5 @@
-"""Design simulation: passes per query against the number of candidates speculated on per pass (replays
+"""(test infrastructure: uses the oracle's restatement; run from the repo root)
+Design simulation: passes per query against the number of candidates speculated on per pass (replays
 the reference traversal with oracle/restate_np.py on a 200k-point index)."""
 import sys, time, pickle, os
 sys.path.insert(0,'.')
