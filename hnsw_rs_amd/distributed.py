@@ -236,9 +236,6 @@ class PipelinedShardedSearch:
             for j in range(g):
                 r = self.res[b][j]
                 self.search_step(self.q[b][j], r[0], r[1], self.stats[b][j], L.compute)
-            # failed queries of the group, on the device, next to the results
-            bad = torch.count_nonzero(self.stats[b][:g, :, 3]).to(torch.int32)
-            self.res[b][self.G].view(-1)[0:1].copy_(bad.view(1))
         L.record(L.compute, self.ev_r[b])
 
     def _gather(self, k, g):
@@ -246,6 +243,10 @@ class PipelinedShardedSearch:
         L = self.lanes
         with L.on(L.comm):
             L.wait(L.comm, self.ev_r[b])
+            # failed queries of the group, counted on the device next to the results -- on this lane: three
+            # small kernels behind the last search of every group kept the compute lane idle for ~40 us
+            bad = torch.count_nonzero(self.stats[b][:g, :, 3]).to(torch.int32)
+            self.res[b][self.G].view(-1)[0:1].copy_(bad.view(1))
             src = self.res[b]
             if self.rank == self.root:
                 dist.gather(src, list(self.out[b].unbind(0)), dst=self.root, group=self.group)
