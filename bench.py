@@ -557,11 +557,13 @@ def main():
         dist.broadcast(t, src=0)
         ef = int(t.item())
     local_search = make_device_search(index, n, ef, B, dev)
-    G = 8  # steps per exchange group (bucketed collectives)
+    G = int(os.environ.get("HNSW_BENCH_GROUP", "8"))  # steps per exchange group (bucketed collectives)
     pipe = PipelinedShardedSearch.from_index(index, d, n, ef, B, dev, group_steps=G) if use_dist else None
     K, W = args.steps, args.warmup
 
     def run_dist(first, count):
+        # (starting with smaller groups so that the first, un-overlapped scatter is short was measured: no gain --
+        # a 20-step run loses its ~0.5 ms to the host enqueueing the first group and to the closing barrier)
         i = first
         while i < first + count:
             g = min(G, first + count - i)
@@ -571,15 +573,16 @@ def main():
                     qg = torch.stack([c.dQ[(i + j) % nqb] for j in range(g)], 0)
             pipe.submit(qg, g)  # scatter / searches / gather of neighbouring groups overlap
             i += g
+        return g  # steps in the last group
 
     if pipe is None:
         elapsed, kern_ms = time_local(c, local_search, K, W)
     else:
-        run_dist(0, W)
+        g_last = run_dist(0, W) if W > 0 else 0
         pipe.finish()
         if rank == 0 and W > 0:  # the exchange returns what a local search returns
             last = W - 1
-            chk_ids, chk_d = pipe.results(pipe.n_groups - 1, last % G)
+            chk_ids, chk_d = pipe.results(pipe.n_groups - 1, g_last - 1)
             ref_ids, ref_d = local_search(c.dQ[last % nqb][:B].contiguous())
             torch.cuda.synchronize()
             assert torch.equal(chk_ids[:B], ref_ids) and torch.equal(chk_d[:B], ref_d), "gathered != local"
