@@ -592,10 +592,18 @@ def main():
         dist.barrier()
         t_start = time.perf_counter()
         run_dist(W, K)  # exactly K steps
+        t_a = time.perf_counter()
         pipe.finish()
+        t_b = time.perf_counter()
         torch.cuda.synchronize()
+        t_c = time.perf_counter()
         dist.barrier()
         elapsed = time.perf_counter() - t_start
+        if os.environ.get("HNSW_BENCH_TRACE") == "1":
+            log("rank %d timed region: enqueue %.0f us, finish (last gather + drain + check) %.0f us, synchronize %.0f us, "
+                "barrier %.0f us, total %.0f us for %d steps" % (rank, (t_a - t_start) * 1e6, (t_b - t_a) * 1e6,
+                                                              (t_c - t_b) * 1e6, (t_start + elapsed - t_c) * 1e6,
+                                                              elapsed * 1e6, K))
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
