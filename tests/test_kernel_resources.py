@@ -1,0 +1,39 @@
+"""Compile-time properties the measured performance of the timed kernels rests on (no GPU needed: hipcc
+cross-compiles for gfx950).  Round 2 found the f32 kernel at 256 VGPRs + 84 AGPRs, one wave per SIMD, with a
+v_accvgpr_read per element in its distance chain, because its row registers were defined under one exec mask and
+consumed under another; this test keeps that from coming back unnoticed."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_lean_kernels_fit_two_waves_per_simd_without_agprs_or_scratch(tmp_path):
+    src = os.path.join(ROOT, "hnsw_rs_amd", "csrc", "search_lean.hip")
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950",
+           "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", str(tmp_path / "lean.o"),
+           "-Rpass-analysis=kernel-resource-usage"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    kernels, cur = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    timed = {k: v for k, v in kernels.items() if "hx_lean_f32_kernel" in k or "hx_lean_q8_kernel" in k}
+    assert len(timed) == 4, sorted(kernels)  # f32 and quant8, one and two list registers
+    for name, r in timed.items():
+        assert r.get("AGPRs", 0) == 0, (name, r)
+        assert r.get("ScratchSize", 0) == 0 and r.get("VGPRs Spill", 0) == 0, (name, r)
+        assert r.get("Occupancy", 0) >= 2, (name, r)
+        assert r.get("VGPRs", 999) <= 240, (name, r)
