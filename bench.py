@@ -354,8 +354,11 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
         from hnsw_rs_amd.distributed import make_device_search
         ls64 = make_device_search(index, n, 64, B, c.dev)
         el64, ms64 = time_local(c, ls64, 50, 5)
+        st64 = ls64.stats[:B].cpu().numpy().astype(np.float64)  # the last launch's traversal counters
+        bq64 = st64[:, 0] * row_bytes + st64[:, 1] * 4 + st64[:, 2] * 4 + 4 * d + 8 * n
         out["at_configured_efSearch_64"] = {"queries_per_s_per_gpu": round(50 * B / el64, 1),
                                             "ms_per_step": round(el64 / 50 * 1e3, 5), "kernel_ms": round(ms64, 5),
+                                            "hbm_frac_algorithmic": round(float(bq64.mean() * B) / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                             "recall_at_%d" % n: recall_by_ef[64]}
     # Not the metric: the same 1024-query launches with several batches in flight (one stream each).
     # A 1024-query launch puts one wave on every SIMD; independent batches share the SIMDs and hide each
