@@ -212,6 +212,45 @@ impl HNSW {
         Graph { index: self, level: layer_nb, m: unsafe { hnsw_layer_m(self.handle, layer_nb as u32) } as usize }
     }
 
+    /// template.rs:158-163: one line per node of the layer with its degree
+    pub fn layer_degrees(&self, layer_nb: usize) {
+        let layer = self.get_layer(layer_nb);
+        for node in layer.iter_nodes() {
+            println!("{}", layer.degree(node).unwrap());
+        }
+    }
+
+    /// template.rs:372-384: the same lines in the same order
+    pub fn print_index(&self) {
+        println!("m = {}", self.params.m);
+        println!("mmax = {}", self.params.mmax);
+        println!("mmax0 = {}", self.params.mmax0);
+        println!("ml = {}", self.params.ml);
+        println!("ef_cons = {}", self.params.ef_cons);
+        let nb_layers = unsafe { hnsw_layer_count(self.handle) } as usize;
+        println!("Nb. layers = {}", nb_layers);
+        println!("Nb. of points = {}", self.len());
+        for idx in 0..nb_layers {
+            println!("NB. nodes in layer {idx}: {}", self.get_layer(idx).nb_nodes());
+        }
+        println!("ep: {:?}", self.params.ep);
+    }
+
+    /// New: exact k nearest stored points of each query under the index's own metric (the reference's
+    /// `helpers::glove::brute_force_nns`, glove.rs:73-109, as one GPU scan): ids and distances, row-major
+    pub fn brute_force(&self, queries: &[f32], k: usize) -> Result<(Vec<NodeID>, Vec<f32>), String> {
+        let nq = queries.len() / self.params.dim;
+        let mut ids = vec![u32::MAX; nq * k];
+        let mut dists = vec![f32::INFINITY; nq * k];
+        let rc = unsafe {
+            hnsw_brute_force_fast(self.handle, queries.as_ptr(), nq as u64, k as u32, ids.as_mut_ptr(), dists.as_mut_ptr())
+        };
+        if rc != HNSW_OK {
+            return Err(last_error());
+        }
+        Ok((ids, dists))
+    }
+
     pub fn assert_param_compliance(&self) {
         let mut ok = 0;
         unsafe { hnsw_check_param_compliance(self.handle, &mut ok) };
@@ -239,6 +278,32 @@ impl HNSW {
         }
         Ok(Self::from_handle(h))
     }
+}
+
+/// template.rs:623-628: M = 12, one build thread
+pub fn make_rand_index_full(n: usize, dim: usize) -> HNSW {
+    HNSW::new(12, None, dim).insert_bulk(make_rand_vectors(n, dim), 1, false).unwrap()
+}
+
+/// template.rs:630-638: n vectors of dim values uniform in [0, 1).  The reference draws from
+/// `rand::thread_rng()` (unseeded); the shim has no dependencies, so it runs a splitmix64 stream seeded
+/// from the clock and takes the top 24 bits of each word, the same `bits * 2^-24` mapping rand uses.
+pub fn make_rand_vectors(n: usize, dim: usize) -> Vec<Vec<f32>> {
+    let mut state = std::time::SystemTime::now()
+        .duration_since(std::time::UNIX_EPOCH)
+        .map(|d| d.as_nanos() as u64)
+        .unwrap_or(0x5EED_0001)
+        ^ (&n as *const usize as u64);
+    let mut next = move || {
+        state = state.wrapping_add(0x9E37_79B9_7F4A_7C15);
+        let mut z = state;
+        z = (z ^ (z >> 30)).wrapping_mul(0xBF58_476D_1CE4_E5B9);
+        z = (z ^ (z >> 27)).wrapping_mul(0x94D0_49BB_1331_11EB);
+        z ^ (z >> 31)
+    };
+    (0..n)
+        .map(|_| (0..dim).map(|_| (next() >> 40) as f32 * (1.0 / 16_777_216.0)).collect())
+        .collect()
 }
 
 impl Clone for HNSW {

@@ -1,11 +1,22 @@
-//! Drop-in replacement for the reference's `hnsw` crate (`hnsw/src/lib.rs`): same module paths
-//! `hnsw::template::HNSW` and `hnsw::params::Params`, same method names and signatures,
-//! implemented on the C ABI of libhnsw_mi355x.so (include/hnsw_mi355x.h).  Callers such as
-//! `eval_glove/src/main.rs:37-41` and `hnsw/benches/hnsw_benchmarks.rs:16-25` compile against it
-//! unchanged.  (The files are named after what they hold -- an FFI handle wrapper -- and mounted at
-//! the reference's module paths here.)
+//! Drop-in replacement for the reference's `hnsw` crate (`hnsw/src/lib.rs`): the module paths its
+//! callers import -- `hnsw::template::HNSW`, `hnsw::params::Params`, `hnsw::helpers::glove::load_glove_array`,
+//! `hnsw::helpers::args::parse_args_eval` (eval_glove/src/main.rs:8-11, hnsw/benches/hnsw_benchmarks.rs:2-3)
+//! -- with the same names and signatures, implemented on the C ABI of libhnsw_mi355x.so
+//! (include/hnsw_mi355x.h).  Source only: the build image has no rustc, so this crate has never been
+//! compiled (tests/test_shim_surface.py checks the public surface against the reference's by name).
+//! The files are named after what they hold and mounted at the reference's module paths here.
+//! Not carried over: `hnsw::disk` (private dead code in the reference), `helpers::get_progress_bar`
+//! (returns an indicatif type), `helpers::data::load_bf_data` (reads the author's home directory).
 pub mod ffi;
 #[path = "gpu_params.rs"]
 pub mod params;
 #[path = "gpu_index.rs"]
 pub mod template;
+pub mod helpers {
+    #[path = "../cli_args.rs"]
+    pub mod args;
+    #[path = "../glove_text.rs"]
+    pub mod glove;
+    #[path = "../data_split.rs"]
+    pub mod data;
+}
