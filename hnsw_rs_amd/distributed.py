@@ -167,16 +167,22 @@ class PipelinedShardedSearch:
 
     ids and dists travel in ONE gather (a [G, 2, s, n] int32 buffer: ids, then the distance bits).
     Every step has its own statistics buffer; the number of queries of a group that did not finish with
-    status 0 (visited table overflow, NaN) travels back with the results, and the root raises on the first
-    group that reports any -- a failed query never comes back as a row of padding ids.
+    status 0 (visited table overflow, NaN) travels back with the results -- a failed query never comes back
+    as a row of padding ids.  Failure is COLLECTIVE: only the root sees the words, so it never raises in the
+    middle of the agreed sequence of collectives (the other ranks would enter the next scatter / gather and
+    wait for the RCCL timeout); it records the first failing group (`failure`, readable any time on the
+    root), every rank keeps issuing the same collectives, and `finish()` -- which every rank calls -- ends
+    with a one-word broadcast from the root after which EVERY rank raises.
     `submit(Q_root, g)` enqueues a group of g steps; `results(k)` (root only) returns the group's
     outputs, valid until `depth` more groups have been submitted; `finish()` drains everything and raises
-    if any query of any group failed.
+    on every rank if any query of any group failed.  depth >= 2: a group's failure word is read one submit
+    after its gather was enqueued, from a buffer the next gather of the same slot overwrites.
 
     search_step(q [s, dim], ids_out [s, n] int32, dist_bits_out [s, n] int32, stats_out [s, 4] int32, lane)
     enqueues one search on `lane`; `from_index` wraps the HIP path."""
 
     def __init__(self, search_step, dim, n, shard, device, group_steps=8, depth=2, group=None, root=0, lanes=None):
+        assert depth >= 2, "depth 1 would let a gather overwrite the failure word of the group before it"
         self.search_step, self.dim, self.n, self.s = search_step, dim, n, shard
         self.device, self.group, self.root, self.depth, self.G = device, group, root, depth, group_steps
         self.world = dist.get_world_size(group)
@@ -205,6 +211,7 @@ class PipelinedShardedSearch:
         self.pending = None  # (group index, steps) whose gather has not been enqueued yet
         self.gathered = []   # groups gathered but not yet checked: (group index, steps)
         self.n_groups = 0
+        self.failure = None  # root: (group index, failed queries per rank) of the first failing group
 
     @staticmethod
     def from_index(index, dim, n, ef, shard, device, **kw):
@@ -258,7 +265,8 @@ class PipelinedShardedSearch:
         self.gathered.append((k, g))
 
     def _check(self, keep_last=0):
-        """root: raise if a gathered group reports failed queries (reads one word per rank and group)"""
+        """root: note the first gathered group that reports failed queries (one word per rank and group).
+        Nothing is raised here: see the class comment."""
         while len(self.gathered) > keep_last:
             k, g = self.gathered.pop(0)
             if self.rank != self.root:
@@ -266,9 +274,8 @@ class PipelinedShardedSearch:
             if self.ev_c[k % self.depth] is not None:
                 self.ev_c[k % self.depth].synchronize()  # the word has landed; nothing else is waited for
             bad = self.bad_host[k % self.depth].clone()
-            if int(bad.sum()) != 0:
-                raise RuntimeError("group %d: %s queries per rank did not finish with status 0 (visited table "
-                                   "overflow or NaN); re-run them through hnsw_search_batch" % (k, bad.tolist()))
+            if int(bad.sum()) != 0 and self.failure is None:
+                self.failure = (k, bad.tolist())
 
     def submit(self, Q_root, g):
         """Q_root: [g, world * shard, dim] on the root (None elsewhere), 1 <= g <= group_steps."""
@@ -289,6 +296,17 @@ class PipelinedShardedSearch:
             self.pending = None
         self.lanes.drain()
         self._check()
+        # the verdict reaches every rank: one word from the root, once per run, after the last collective
+        # of the agreed sequence
+        word = torch.zeros(2, dtype=torch.int32, device=self.device)
+        if self.rank == self.root and self.failure is not None:
+            word[0], word[1] = 1, self.failure[0]
+        dist.broadcast(word, src=self.root, group=self.group)
+        w = word.cpu()
+        if int(w[0]) != 0:
+            detail = (" %s queries per rank" % (self.failure[1],)) if self.failure is not None else ""
+            raise RuntimeError("group %d:%s did not finish with status 0 (visited table overflow or NaN); "
+                               "re-run them through hnsw_search_batch" % (int(w[1]), detail))
 
     def results(self, k, j):
         """(ids [W*s, n] int32, dists [W*s, n] f32) of step j of group k, on the root"""

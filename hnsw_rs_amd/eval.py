@@ -12,6 +12,7 @@ Exact nearest neighbours come from the engine's own exhaustive GPU scan under th
 """
 import argparse
 import ctypes
+import re
 import sys
 import time
 
@@ -21,11 +22,15 @@ from . import VEC_F32, VEC_QUANT8
 from .hnsw import HNSW
 
 
+# the grammar of Rust's `impl FromStr for f32`: sign, then inf / infinity / nan (any case) or a decimal
+# number with an optional exponent; no surrounding whitespace, no underscores, no hex (Python's float()
+# would take "1_0" and " 1")
+_RUST_F32 = re.compile(r"[+-]?(?:inf|infinity|nan|(?:[0-9]+\.?[0-9]*|\.[0-9]+)(?:[eE][+-]?[0-9]+)?)\Z", re.IGNORECASE)
+
+
 def _parse_f32(tok):
     """Rust's str::parse::<f32>: correctly rounded decimal -> f32 (glibc strtof), None if not a number"""
-    try:
-        float(tok)
-    except ValueError:
+    if not _RUST_F32.match(tok):
         return None
     libc = _parse_f32.libc
     if libc is None:
@@ -40,7 +45,9 @@ _parse_f32.libc = None
 
 def load_glove_array(lim, path, verbose=False):
     """-> (words, embeddings [n, d] float32).  lim = 0 reads every line.  A token that does not parse
-    as f32 is appended to the word (glove.rs:44-54); rows of unequal length are an error."""
+    as f32 is appended to the word (glove.rs:44-54); a row whose length differs from the first row's is an
+    error, checked like the reference from the third row on (glove.rs:57 tests `embeddings.len() > 1`; a
+    ragged second row surfaces when the array is formed)."""
     words, rows = [], []
     with open(path) as f:
         for idx, line in enumerate(f):
@@ -54,13 +61,15 @@ def load_glove_array(lim, path, verbose=False):
                     word += tok
                 else:
                     vals.append(v)
-            if rows and len(vals) != len(rows[0]):
+            if len(rows) > 1 and len(vals) != len(rows[0]):
                 raise ValueError("Line %d: vector is not the same size as others. Len: %d, Word %s" % (
                     idx + 1, len(vals), word))
             rows.append(vals)
             words.append(word)
             if verbose and idx % 10000 == 0:
                 print("\rLoading Embeddings %d" % idx, end="", file=sys.stderr)
+    if len(rows) > 1 and len(rows[1]) != len(rows[0]):
+        raise ValueError("Line 2: vector is not the same size as others. Len: %d, Word %s" % (len(rows[1]), words[1]))
     return words, np.array(rows, dtype=np.float32)
 
 

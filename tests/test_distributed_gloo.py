@@ -93,12 +93,14 @@ def _pipe_worker(rank, world, port, outfile, inject_failure):
         stats_out.zero_()
         stats_out[:, :3] = torch.from_numpy(st.astype(np.int64)).to(torch.int32)
         calls["n"] += 1
-        if inject_failure and rank == 1 and calls["n"] == 3:
-            stats_out[2, 3] = -7  # one query of one step on the non-root rank reports an overflow
+        if inject_failure and rank == 1 and calls["n"] == 1:
+            # one query of the FIRST group on the non-root rank reports an overflow: the root learns it with
+            # three more groups of collectives still to come, and must not leave the sequence
+            stats_out[2, 3] = -7
 
     pipe = PipelinedShardedSearch(search_step, d, k, shard, torch.device("cpu"), group_steps=G, depth=2,
                                   lanes=InlineLanes())
-    steps = 5  # groups of 2, 2 and 1 steps: the last group is a partial one
+    steps = 7  # groups of 2, 2, 2 and 1 steps: the last group is a partial one
     Q = torch.from_numpy(rand_vectors(steps * world * shard, d, 2)).view(steps, world * shard, d)
     got, failed = {}, ""
     try:
@@ -116,15 +118,19 @@ def _pipe_worker(rank, world, port, outfile, inject_failure):
         ok = True
         if not inject_failure:
             # the last `depth` groups are still held: check them against a direct search
-            for kk, first, g in ((1, 2, 2), (2, 4, 1)):
+            for kk, first, g in ((2, 4, 2), (3, 6, 1)):
                 for j in range(g):
                     ids, dists = pipe.results(kk, j)
                     w_ids, w_d, _, _ = orc.search_batch(Q[first + j].numpy(), k, ef)
                     ok &= np.array_equal(ids.numpy().astype(np.uint32), w_ids) and np.array_equal(dists.numpy(), w_d)
             ok &= failed == ""
         else:
-            ok = "did not finish with status 0" in failed
+            ok = "group 0:" in failed and "did not finish with status 0" in failed and pipe.failure == (0, [0, 1])
         open(outfile, "w").write("ok" if ok else "mismatch: " + failed)
+    else:
+        # the failure is collective: the other rank issued every collective of the sequence (or this
+        # process would hang in the gloo timeout) and raised too
+        open(outfile + ".rank%d" % rank, "w").write(failed)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -136,3 +142,5 @@ def test_pipelined_bucketed_exchange_world_size_2_gloo(tmp_path, inject_failure)
     out = str(tmp_path / "result.txt")
     mp.spawn(_pipe_worker, args=(2, _free_port(), out, inject_failure), nprocs=2, join=True)
     assert open(out).read() == "ok"
+    other = open(out + ".rank1").read()
+    assert ("group 0:" in other and "did not finish with status 0" in other) if inject_failure else other == ""
