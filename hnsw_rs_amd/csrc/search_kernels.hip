@@ -515,6 +515,8 @@ __device__ __forceinline__ float f32_row_sum_staged(const uint4 *src, const floa
     return s;
 }
 
+#include "coop_rows.inc"
+
 // ---------------------------------------------------------------------------------------------
 // Distance of a stored point to the staged row on the build path.  DS > 0: the dimension is a
 // compile-time constant (all row pieces in flight, dead elements vanish), otherwise the runtime
@@ -823,9 +825,15 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
             dist = __builtin_sqrtf(s);
         } else if (KIND == HNSW_VEC_F32 && P > 0 && DS > 0) {
             float sm = 0.0f;
-            if (active) {
+            if constexpr (coop_rows<KIND, DS>()) {
+                // whole-line rows: eight lanes to a 128-byte line, owners sum out of an LDS image
+                sm = f32_rows_coop<(DS > 0 ? DS : 32), HX_COOP_K>(v.rows, id, active, yq,
+                                                                 reinterpret_cast<uint32_t *>(perm), spec_buf, lane);
+            } else if (active) {
                 const uint4 *src = reinterpret_cast<const uint4 *>(v.rows + (size_t)id * v.row_stride);
-                if constexpr (P > 48) {
+                if constexpr (coop_rows<KIND, DS>()) {
+                    // (never reached: the cooperative gather below runs outside the lane mask)
+                } else if constexpr (P > 48) {
                     sm = f32_row_sum_staged<(DS > 0 ? DS : 1), HX_WIDE_CH, true>(src, yq);
                 } else {
                     uint4 w[P > 0 ? P : 1];
@@ -2488,6 +2496,7 @@ static int launch_one(const DevView &v, const SearchArgs &a, uint32_t nblocks, u
         (KIND == HNSW_VEC_QUANT8) ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4;
     size_t lds = (4ull << slots_log2) + 64ull * R * 8 + ((yq_bytes + 15) & ~15ull);
     if (FAT) lds += 2ull * 1024 * (P > 0 ? P : 1);
+    if (coop_rows<KIND, DS>()) lds += HX_COOP_IMG_BYTES;  // the stage image of f32_rows_coop (rank -> id words live in perm)
     auto kern = hx_search_kernel<KIND, P, DS, R, FAT>;
     if (lds > 160 * 1024) {
         set_error("search needs %zu bytes of LDS (> 160 KiB)", lds);

@@ -174,9 +174,19 @@ struct Visited {
 #endif
 template <int R>
 struct Lst {
+    static constexpr int NR = R;  // list registers per lane
+    struct Masks {
+        u64 U[R];
+    };
     u64 L[R];
     uint32_t n_cur;  // wave-uniform
     u64 last_key;    // key (flag dropped) of entry ef - 1 when the list is full, else LK_INVALID
+
+    static __device__ __forceinline__ uint32_t idx_of(int r, int lane) { return (uint32_t)(R * lane + r); }
+    __device__ __forceinline__ void set_first(u64 key, int lane) {
+        if (lane == 0) L[0] = key;
+        n_cur = 1;
+    }
 
     __device__ __forceinline__ void init() {
 #pragma unroll
@@ -197,11 +207,12 @@ struct Lst {
     }
     // ballots of the entries not expanded yet, and "take the smallest of them" on those masks: several
     // picks cost one vector -> scalar hand-off
-    __device__ __forceinline__ void unexp_masks(u64 (&U)[R]) const {
+    __device__ __forceinline__ void unexp_masks(Masks &mk) const {
 #pragma unroll
-        for (int r = 0; r < R; r++) U[r] = __ballot((int32_t)(uint32_t)(L[r] >> 32) >= 0);
+        for (int r = 0; r < R; r++) mk.U[r] = __ballot((int32_t)(uint32_t)(L[r] >> 32) >= 0);
     }
-    static __device__ __forceinline__ int take_first(u64 (&U)[R]) {
+    __device__ __forceinline__ int take_first(Masks &mk) const {
+        u64(&U)[R] = mk.U;
         uint32_t pos = 0xFFFFFFFFu;
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -340,6 +351,152 @@ struct Lst {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// The list for 64 < ef <= 128 as HEAD + TAIL: the 64 smallest entries in one register (entry i = lane
+// i), entries 64 .. ef - 1 in a second one (entry 64 + i = lane i).  With the interleaved two-register
+// list every pick, every mark and every merge touched both registers, and the metric's efSearch 68 --
+// four entries past one register -- paid 8.7 % for 1.3 % more work (profiles/r02_ef_sweep.txt).  Here the
+// candidates are picked and marked in the head alone (the tail is looked at only once the head holds
+// nothing unexpanded, i.e. in a query's last picks), a merge that inserts nothing touches neither, an
+// insertion into the head hands the entry that falls off its end to the tail (one whole-register shift),
+// an insertion beyond entry 63 touches the tail alone.  Same contents, same order, same results as Lst<2>.
+// ---------------------------------------------------------------------------------------------
+struct LstHT {
+    static constexpr int NR = 2;
+    struct Masks {
+        u64 head, tail;
+        bool tail_known;
+    };
+    u64 L[2];  // L[0] = head, L[1] = tail
+    uint32_t n_cur;
+    u64 last_key;
+
+    static __device__ __forceinline__ uint32_t idx_of(int r, int lane) { return (uint32_t)(64 * r + lane); }
+    __device__ __forceinline__ void init() {
+        L[0] = L[1] = LK_INVALID;
+        n_cur = 0;
+        last_key = LK_INVALID;
+    }
+    __device__ __forceinline__ void set_first(u64 key, int lane) {
+        if (lane == 0) L[0] = key;
+        n_cur = 1;
+    }
+    __device__ __forceinline__ void unexp_masks(Masks &mk) const {
+        mk.head = __ballot((int32_t)(uint32_t)(L[0] >> 32) >= 0);
+        mk.tail = 0;
+        mk.tail_known = false;
+    }
+    // smallest unexpanded entry: in the head while it has one
+    __device__ __forceinline__ int take_first(Masks &mk) const {
+        if (HX_LIKELY(mk.head != 0)) {
+            const int pos = __ffsll((long long)mk.head) - 1;
+            mk.head &= mk.head - 1;
+            return pos;
+        }
+        if (!mk.tail_known) {
+            mk.tail = n_cur > 64 ? __ballot((int32_t)(uint32_t)(L[1] >> 32) >= 0) : 0ull;
+            mk.tail_known = true;
+        }
+        if (mk.tail == 0) return -1;
+        const int pos = __ffsll((long long)mk.tail) - 1;
+        mk.tail &= mk.tail - 1;
+        return 64 + pos;
+    }
+    __device__ __forceinline__ uint32_t id_at(uint32_t pos) const {
+        const uint32_t a = rdlane((uint32_t)L[0], pos & 63u), b = rdlane((uint32_t)L[1], pos & 63u);
+        return pos < 64u ? a : b;
+    }
+    __device__ __forceinline__ u64 key_at(uint32_t pos) const {
+        const u64 a = rdlane64(L[0], pos & 63u), b = rdlane64(L[1], pos & 63u);
+        return pos < 64u ? a : b;
+    }
+    __device__ __forceinline__ void mark(uint32_t pos, int lane) {
+        if ((uint32_t)lane == pos) L[0] |= LK_EXPANDED;
+        if ((uint32_t)lane + 64u == pos) L[1] |= LK_EXPANDED;
+    }
+    __device__ __forceinline__ void refresh_last(uint32_t ef) {
+        // ef > 64: entry ef - 1 lives in the tail
+        last_key = n_cur >= ef ? (rdlane64(L[1], (ef - 65u) & 63u) & LK_MASK) : LK_INVALID;
+    }
+    static __device__ __forceinline__ u64 shr1(u64 v) {  // lane i takes lane i - 1's value (lane 0: 0)
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138, 0xF, 0xF, false);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
+        return ((u64)hi << 32) | lo;
+    }
+
+    __device__ __forceinline__ void merge(u64 key, uint32_t ef, u64 *perm, int lane) {
+        const bool surv = key < last_key;  // last_key is LK_INVALID while the list is not full
+        const u64 smask = __ballot(surv);
+        if (smask == 0) return;
+        const uint32_t m = (uint32_t)__popcll(smask);
+        if (m <= HX_MERGE_SHIFT_MAX) {
+            u64 it = smask;
+            while (it) {
+                const uint32_t j = (uint32_t)__ffsll((long long)it) - 1;
+                it &= it - 1;
+                const u64 e = rdlane64(key, j);
+                if (!(e < last_key)) continue;  // the first insert tightened the bound
+                const uint32_t pos = (uint32_t)__popcll(__ballot((L[0] & LK_MASK) < e));
+                if (pos < 64u) {
+                    // into the head: its last entry moves to the front of the tail
+                    const u64 carry = rdlane64(L[0], 63);
+                    const u64 below = shr1(L[0]);
+                    L[0] = (uint32_t)lane < pos ? L[0] : ((uint32_t)lane == pos ? e : below);
+                    const u64 tb = shr1(L[1]);
+                    L[1] = lane == 0 ? carry : tb;
+                } else {
+                    const uint32_t tpos = (uint32_t)__popcll(__ballot((L[1] & LK_MASK) < e));
+                    const u64 tb = shr1(L[1]);
+                    L[1] = (uint32_t)lane < tpos ? L[1] : ((uint32_t)lane == tpos ? e : tb);
+                }
+                n_cur = min(n_cur + 1, ef);
+                if (64u + (uint32_t)lane >= ef) L[1] = LK_INVALID;
+                refresh_last(ef);
+            }
+            return;
+        }
+        // Three or more: the rank / scatter merge of Lst<R> over the two registers (perm: 128 entries,
+        // sv: the 64 behind them)
+        u64 *sv = perm + 128;
+        const u64 Mm = L[0] & LK_MASK, Tm = L[1] & LK_MASK;
+        uint32_t sh0 = 0, sh1 = 0, srank = 0;
+        u64 it = smask;
+        while (it) {
+            const uint32_t j = (uint32_t)__ffsll((long long)it) - 1;
+            it &= it - 1;
+            const u64 e = rdlane64(key, j);
+            sh0 += e < Mm ? 1u : 0u;
+            sh1 += e < Tm ? 1u : 0u;
+            srank += e < key ? 1u : 0u;
+        }
+        const uint32_t n_new = min(n_cur + m, ef);
+        perm[lane] = LK_INVALID;
+        perm[64 + lane] = LK_INVALID;
+        asm volatile("" ::: "memory");  // LDS serves a wave's requests in order
+        {
+            const uint32_t i0 = (uint32_t)lane, i1 = 64u + (uint32_t)lane;
+            if (i0 < n_cur && i0 + sh0 < n_new) perm[i0 + sh0] = L[0];
+            if (i1 < n_cur && i1 + sh1 < n_new) perm[i1 + sh1] = L[1];
+        }
+        if (surv) sv[srank] = key;
+        asm volatile("" ::: "memory");
+        u64 v0 = perm[lane], v1 = perm[64 + lane];
+        const bool hole0 = v0 == LK_INVALID && (uint32_t)lane < n_new;
+        const bool hole1 = v1 == LK_INVALID && 64u + (uint32_t)lane < n_new;
+        const u64 H0 = __ballot(hole0), H1 = __ballot(hole1);
+        const uint32_t hr0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(H0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)H0, 0u));
+        const uint32_t hr1 = (uint32_t)__popcll(H0) +
+                             __builtin_amdgcn_mbcnt_hi((uint32_t)(H1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)H1, 0u));
+        if (hole0) v0 = sv[hr0];
+        if (hole1) v1 = sv[hr1];
+        L[0] = v0;
+        L[1] = v1;
+        n_cur = n_new;
+        lds_fence();
+        refresh_last(ef);
+    }
+};
+
 // FullVec::distance of one row per lane against the query held in registers (full.rs:23-29): x - y and
 // the square two elements per instruction (each element the same single-rounded IEEE operations), the
 // sum one serial chain in element order.  No exec mask of its own: the callers request the row's DS / 4
@@ -377,8 +534,9 @@ __device__ __forceinline__ float row_dist(const float *rows, uint32_t id, bool w
     return __builtin_sqrtf(s);
 }
 
-template <int DS, int R>
+template <int DS, class LT>
 __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
+    constexpr int R = LT::NR;
     static_assert(DS % 4 == 0, "whole 16-byte pieces");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -534,7 +692,7 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
     dbg_acc[7] = __builtin_readcyclecounter() - t_begin;  // query staging + entry point + upper layers
 #endif
     const uint32_t ef = max(1u, a.ef);
-    Lst<R> lst;
+    LT lst;
     lst.init();
     if (status == HNSW_OK) {
         vis.bshift = 32 - (a.slots_log2 - 2);
@@ -543,8 +701,7 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
         vis.clear(hslots, lane);
         vis.insert(cur, lane == 0);
         n_vis = 1;
-        if (lane == 0) lst.L[0] = best;
-        lst.n_cur = 1;
+        lst.set_first(best, lane);
         lst.refresh_last(ef);
         const uint32_t S0 = a.S0;
         const bool upper = lane >= 32;
@@ -568,11 +725,11 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
                 ovf_lo += 32;
             } else {
                 // ---- pick c (the smallest unexpanded entry) and the runner-up p: one set of ballots ----
-                u64 U[R];
+                typename LT::Masks U;
                 lst.unexp_masks(U);
-                const int cpos = Lst<R>::take_first(U);
+                const int cpos = lst.take_first(U);
                 if (HX_UNLIKELY(cpos < 0)) break;  // candidates exhausted / only worse ones left (searcher.rs:35,41-44)
-                ppos = Lst<R>::take_first(U);
+                ppos = lst.take_first(U);
                 const uint32_t cid = lst.id_at((uint32_t)cpos);
                 if (ppos >= 0) pid = lst.id_at((uint32_t)ppos);
                 lst.mark((uint32_t)cpos, lane);
@@ -676,18 +833,18 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
             }
             // ---- is p the next candidate?  then commit it from the registers ----
             if (HX_UNLIKELY(!spec_ok)) continue;
-            u64 V[R];
+            typename LT::Masks V;
             lst.unexp_masks(V);
-            const int npos = Lst<R>::take_first(V);
+            const int npos = lst.take_first(V);
             if (HX_UNLIKELY(npos < 0)) break;
             if (HX_UNLIKELY(lst.id_at((uint32_t)npos) != pid)) continue;
             // The pass after this one will most likely expand the two entries that follow p (measured:
             // three times out of four when p is committed).  Their adjacency rows are requested now and
             // land while p is being committed; if the next pick is a different pair they are dropped.
             {
-                const int apos = Lst<R>::take_first(V);
+                const int apos = lst.take_first(V);
                 if (HX_LIKELY(apos >= 0)) {
-                    const int bpos = Lst<R>::take_first(V);
+                    const int bpos = lst.take_first(V);
                     pre_c = lst.id_at((uint32_t)apos);
                     pre_p = bpos >= 0 ? lst.id_at((uint32_t)bpos) : HX_EMPTY_SLOT;
                     pre_nb = HX_EMPTY_SLOT;
@@ -738,7 +895,7 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
     const uint32_t count = status == HNSW_OK ? min(a.n, lst.n_cur) : 0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const uint32_t idx = (uint32_t)(R * lane + r);
+        const uint32_t idx = LT::idx_of(r, lane);
         if (idx < a.n) {
             const bool have = idx < count;
             a.out_ids[(size_t)q * a.n + idx] = have ? (uint32_t)lst.L[r] : HX_EMPTY_SLOT;
@@ -778,8 +935,9 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
 // evaluated neighbour instead of a whole 4-KiB block per expansion (measured traffic / algorithmic bytes
 // 2.1 there) and needs no 4-GB copy of the rows.
 // =============================================================================================
-template <int R>
+template <class LT>
 __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
+    constexpr int R = LT::NR;
     constexpr int DS = 100, P = 4, NQ = 4 * (DS / 8) + DS % 8;  // 52 query values per half (half 1 uses 48)
     constexpr uint32_t HALF = 64, ROW = 128, NCH4 = 4 * (DS / 8), REM = DS % 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -956,7 +1114,7 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
     dbg_acc[7] = __builtin_readcyclecounter() - t_begin;
 #endif
     const uint32_t ef = max(1u, a.ef);
-    Lst<R> lst;
+    LT lst;
     lst.init();
     if (status == HNSW_OK) {
         vis.bshift = 32 - (a.slots_log2 - 2);
@@ -965,8 +1123,7 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
         vis.clear(hslots, lane);
         vis.insert(cur, lane == 0);
         n_vis = 1;
-        if (lane == 0) lst.L[0] = best;
-        lst.n_cur = 1;
+        lst.set_first(best, lane);
         lst.refresh_last(ef);
         const uint32_t S0 = a.S0;
         uint32_t pre_nb = HX_EMPTY_SLOT, pre_c = HX_EMPTY_SLOT;  // adjacency row requested ahead
@@ -979,11 +1136,11 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
         // f32 kernel's two-candidate pass with the wanted rows packed onto the pairs: + 6 to + 10 %.)
         while (true) {
             STAMP(f0);
-            u64 U[R];
+            typename LT::Masks U;
             lst.unexp_masks(U);
-            const int cpos = Lst<R>::take_first(U);
+            const int cpos = lst.take_first(U);
             if (cpos < 0) break;  // candidates exhausted / only worse ones left (searcher.rs:35,41-44)
-            const int ppos = Lst<R>::take_first(U);
+            const int ppos = lst.take_first(U);
             const uint32_t cid = lst.id_at((uint32_t)cpos);
             lst.mark((uint32_t)cpos, lane);
             n_exp++;
@@ -1080,7 +1237,7 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
     const uint32_t count = status == HNSW_OK ? min(a.n, lst.n_cur) : 0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const uint32_t idx = (uint32_t)(R * lane + r);
+        const uint32_t idx = LT::idx_of(r, lane);
         if (idx < a.n) {
             const bool have = idx < count;
             a.out_ids[(size_t)q * a.n + idx] = have ? (uint32_t)lst.L[r] : HX_EMPTY_SLOT;
@@ -1110,10 +1267,11 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
     }
 }
 
-template <int R>
+template <class LT>
 int launch_lean_q8(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
+    constexpr int R = LT::NR;
     const size_t lds = (4ull << a.slots_log2) + (64ull * R + 64) * 8 + 2 * 56 * 4;
-    auto kern = hx_lean_q8_kernel<R>;
+    auto kern = hx_lean_q8_kernel<LT>;
     if (lds > 160 * 1024) {
         set_error("search needs %zu bytes of LDS (> 160 KiB)", lds);
         return HNSW_ERR_ARG;
@@ -1135,10 +1293,11 @@ int launch_lean_q8(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
     return HNSW_OK;
 }
 
-template <int DS, int R>
+template <int DS, class LT>
 int launch_lean_one(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
+    constexpr int R = LT::NR;
     const size_t lds = (4ull << a.slots_log2) + (64ull * R + 64) * 8;
-    auto kern = hx_lean_f32_kernel<DS, R>;
+    auto kern = hx_lean_f32_kernel<DS, LT>;
     if (lds > 160 * 1024) {
         set_error("search needs %zu bytes of LDS (> 160 KiB)", lds);
         return HNSW_ERR_ARG;
@@ -1200,12 +1359,16 @@ int launch_lean(const DevView &v, const SearchArgs &s, uint32_t nblocks, uint32_
     a.n = s.n;
     a.slots_log2 = slots_log2;
     a.dbg = s.dbg;
+    // 64 < ef <= 128: head + tail list (HNSW_MI355X_LIST=interleaved: round 2's two-register list, for A/B runs)
+    static const bool interleaved = getenv("HNSW_MI355X_LIST") && getenv("HNSW_MI355X_LIST")[0] == 'i';
     if (v.kind == HNSW_VEC_QUANT8) {
-        if (a.ef <= 64) return launch_lean_q8<1>(a, nblocks, stream);
-        return launch_lean_q8<2>(a, nblocks, stream);
+        if (a.ef <= 64) return launch_lean_q8<Lst<1>>(a, nblocks, stream);
+        if (interleaved) return launch_lean_q8<Lst<2>>(a, nblocks, stream);
+        return launch_lean_q8<LstHT>(a, nblocks, stream);
     }
-    if (a.ef <= 64) return launch_lean_one<100, 1>(a, nblocks, stream);
-    return launch_lean_one<100, 2>(a, nblocks, stream);
+    if (a.ef <= 64) return launch_lean_one<100, Lst<1>>(a, nblocks, stream);
+    if (interleaved) return launch_lean_one<100, Lst<2>>(a, nblocks, stream);
+    return launch_lean_one<100, LstHT>(a, nblocks, stream);
 }
 
 }  // namespace hx
