@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec of the HNSW search hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2|3|4] [--n-points N]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 `python bench.py --gpus N` with N > 1 and no launcher environment starts the N ranks itself (one process
@@ -20,9 +20,17 @@ reference's `VecType = FullVec`, vectors/src/full.rs).  The reference SHIPS `Vec
 (8-bit codes dequantised to f32 on the fly, points/src/point.rs:4); that variant is measured in
 the same run at N = 1 and reported under "quant8_reference_default".  All arithmetic is f32.
 
-Index build is outside the timed region.  N > 1: one process per GPU, index replicated in every
-GPU's HBM, each group of steps' 1024 x N queries scattered from rank 0 and the results gathered
-back over RCCL (weak scaling), exchange and search pipelined on two streams.
+Index build is outside the timed region.  N > 1: one process per GPU; rank 0 builds and the snapshot's
+flat HBM arrays are broadcast to the other ranks over RCCL (HNSW.replicate), each group of steps'
+1024 x N queries scattered from rank 0 and the results gathered back over RCCL (weak scaling),
+exchange and search pipelined on two streams.
+
+--config 3 (BASELINE configs[3]: 100M x 128d, replicated, query-sharded) is the same run at that size,
+with efSearch walked up a coarser ladder.  --config 4 (configs[4]: 50M x 256d index build, points sharded,
+RCCL neighbour all-gather) times the BUILD: every rank holds a replica and calls insert_bulk_sharded, the
+insertion searches of each batch are split over the ranks and their edge records all-gathered; its line's
+value is points inserted per second, with recall and the search rate of the built index beside it.
+`--n-points` scales either down to what one GPU box builds in its time limit (say so in the line).
 
 One JSON line on stdout (rank 0); progress on stderr.
 """
@@ -48,6 +56,7 @@ def kernel_sources_sha16():
         h.update(open(os.path.join(ROOT, "hnsw_rs_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 EF_LADDER = (64, 68, 72, 76, 80, 88, 96, 112, 128, 160, 192, 256)
+EF_LADDER_LARGE = (64, 96, 128, 192, 256)  # configs[3] / [4]: 50-100M points need well beyond 64 for recall 0.99
 
 
 def log(*a):
@@ -90,9 +99,10 @@ def parse():
     p.add_argument("--recall-queries", type=int, default=10240,
                    help="queries the true recall is measured on (all 10 bench batches: standard error 0.0003)")
     p.add_argument("--index-cache", default=os.environ.get("HNSW_BENCH_CACHE", "/tmp/hnsw_bench_cache"))
-    p.add_argument("--config", type=int, default=1, choices=[1, 2],
+    p.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4],
                    help="BASELINE.json configs[i]: 1 = 1M x 100d fp32 L2, efSearch 64 (the metric); 2 = 10M x 768d fp32, "
-                        "unit-normalised rows (cosine order = L2 order), efSearch 128")
+                        "unit-normalised rows (cosine order = L2 order), efSearch 128; 3 = 100M x 128d L2, replicated "
+                        "per GPU, query batch sharded; 4 = 50M x 256d index BUILD sharded over the GPUs")
     p.add_argument("--no-extras", action="store_true",
                    help="skip the PCIe-inclusive rate and the recipe-B efSearch sweep (profiling passes)")
     a = p.parse_args()
@@ -112,6 +122,17 @@ def parse():
         a.unit_rows = True
     else:
         a.unit_rows = False
+    if a.config in (3, 4):  # configs[3] / configs[4]; explicit flags still win
+        argv = " ".join(sys.argv[1:])
+        if "--n-points" not in argv:
+            a.n_points = 100_000_000 if a.config == 3 else 50_000_000
+        if "--dim" not in argv:
+            a.dim = 128 if a.config == 3 else 256
+        if "--recall-queries" not in argv:
+            a.recall_queries = 1024
+        if "--steps" not in argv:
+            a.steps = 50
+        a.no_secondary = True
     return a
 
 
@@ -167,7 +188,9 @@ def make_rows(a, seed, first, n, threads, recipe=None):
 
 
 def get_index(c, kind_name):
-    """rank 0 builds (or loads a cached build) and saves; the other ranks load the same files."""
+    """configs[1..3]: rank 0 builds (or loads a cached build) and the snapshot's flat HBM arrays are broadcast
+    to the other ranks over RCCL (HNSW.replicate: SURVEY.md section 8e).  configs[4]: every rank holds a replica
+    and the build itself is sharded (insert_bulk_sharded), timed into c.build_info."""
     import hnsw_rs_amd as H
     a = c.args
     kind = H.VEC_QUANT8 if kind_name == "quant8" else H.VEC_F32
@@ -179,8 +202,24 @@ def get_index(c, kind_name):
     cache_dir = os.path.join(a.index_cache, tag)
     index = None
     t0 = time.time()
-    if c.rank == 0:
-        if os.path.isdir(cache_dir):
+    sharded_build = a.config == 4 and c.use_dist and not a.cpu_build
+    builder = c.rank == 0 or sharded_build
+
+    def slabs():
+        # rows are generated and handed over in slabs (HNSW::insert_bulk may be called repeatedly,
+        # template.rs:493-504): the host never holds more than one slab beside the index itself
+        slab = a.n_points
+        try:
+            avail = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1]) * 1024
+            if avail < 3 * 4 * a.dim * a.n_points * (c.world if sharded_build else 1):
+                slab = max(1, min(a.n_points, (4 << 30) // (4 * a.dim)))
+        except (OSError, StopIteration, ValueError):
+            pass
+        for first in range(0, a.n_points, slab):
+            yield make_rows(a, 0x5EED0001, first, min(slab, a.n_points - first), min(32, c.ncpu))
+
+    if builder:
+        if a.config != 4 and os.path.isdir(cache_dir):
             try:
                 index = H.HNSW.load(cache_dir)
                 log("loaded cached %s index (%.1fs)" % (kind_name, time.time() - t0))
@@ -188,42 +227,60 @@ def get_index(c, kind_name):
                 log("cache unusable (%s); rebuilding" % e)
                 shutil.rmtree(cache_dir, ignore_errors=True)
         if index is None:
-            t1 = time.time()
             index = H.HNSW.new(a.m, a.ef_cons, a.dim, kind)
             index.set_device(c.local_rank)
             index.set_option("gpu_build_batch_max", bmax)
             index.set_option("gpu_build_batch_div", bdiv)
-            # rows are generated and handed over in slabs (HNSW::insert_bulk may be called repeatedly,
-            # template.rs:493-504): the host never holds more than one slab beside the index itself
-            slab = a.n_points
-            try:
-                avail = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1]) * 1024
-                if avail < 3 * 4 * a.dim * a.n_points:
-                    slab = max(1, min(a.n_points, (4 << 30) // (4 * a.dim)))
-            except (OSError, StopIteration, ValueError):
-                pass
-            for first in range(0, a.n_points, slab):
-                store = make_rows(a, 0x5EED0001, first, min(slab, a.n_points - first), min(32, c.ncpu))
+            build_s, gen_s = 0.0, 0.0
+            tg = time.time()
+            for store in slabs():
+                gen_s += time.time() - tg
+                if sharded_build:
+                    c.dist.barrier()
+                t1 = time.time()
                 if a.cpu_build:
                     index.insert_bulk(store, c.build_threads, False)
+                elif sharded_build:
+                    index.insert_bulk_sharded(store, c.build_threads, False, device="cuda:%d" % c.local_rank)
                 else:
                     index.insert_bulk_device(store, c.build_threads, False)
+                if sharded_build:
+                    c.torch.cuda.synchronize()
+                    c.dist.barrier()
+                build_s += time.time() - t1
+                del store
+                tg = time.time()
+            if sharded_build:  # the build is as long as its slowest rank
+                t = c.torch.tensor([build_s], dtype=c.torch.float64, device=c.dev)
+                c.dist.all_reduce(t, op=c.dist.ReduceOp.MAX)
+                build_s = float(t.item())
+            c.build_info = {"seconds": round(build_s, 3), "points_per_s": round(a.n_points / build_s, 1),
+                            "row_generation_seconds": round(gen_s, 1), "layers": index.nb_layers(),
+                            "form": ("host build" if a.cpu_build else
+                                     "on-device build, insertion searches sharded over %d rank(s), one RCCL all-gather of "
+                                     "edge records per batch (insert_bulk_sharded)" % c.world if sharded_build else
+                                     "on-device build on one GPU (insert_bulk_device)"),
+                            "host_threads": c.build_threads}
             log("built the %s index (%s, %d host threads) in %.1fs, %d layers" % (
-                kind_name, "host build" if a.cpu_build else "on-device build", c.build_threads,
-                time.time() - t1, index.nb_layers()))
-            del store
-            try:
-                os.makedirs(a.index_cache, exist_ok=True)
-                shutil.rmtree(cache_dir, ignore_errors=True)
-                index.save(cache_dir)
-            except (H.HnswError, OSError) as e:
-                log("could not cache the index: %s" % e)
-    if c.world > 1:
+                kind_name, c.build_info["form"], c.build_threads, build_s, index.nb_layers()))
+            if a.config != 4 and c.rank == 0 and a.n_points <= 20_000_000:
+                try:
+                    os.makedirs(a.index_cache, exist_ok=True)
+                    shutil.rmtree(cache_dir, ignore_errors=True)
+                    index.save(cache_dir)
+                except (H.HnswError, OSError) as e:
+                    log("could not cache the index: %s" % e)
+    if c.use_dist and not sharded_build:
+        t1 = time.time()
+        index = H.HNSW.replicate(index, a.m, a.ef_cons, a.dim, kind, src=0, device="cuda:%d" % c.local_rank)
+        c.torch.cuda.synchronize()
         c.dist.barrier()
-        if c.rank != 0:
-            index = H.HNSW.load(cache_dir)  # replicate: every rank holds the same index
-    index.set_device(c.local_rank)
-    index.upload()
+        c.replication = {"seconds": round(time.time() - t1, 3), "how": "RCCL broadcast of the snapshot's flat HBM arrays "
+                         "from rank 0 (hnsw_snapshot_describe / _adopt / _commit)"}
+        log("rank %d: snapshot replicated over RCCL in %.2fs" % (c.rank, time.time() - t1))
+    else:
+        index.set_device(c.local_rank)
+        index.upload()
     log("rank %d: %s index resident in HBM, %.1f MB" % (c.rank, kind_name, index.device_bytes() / 1e6))
     return index, tag
 
@@ -256,14 +313,14 @@ def choose_ef(c, index, kind_name):
 
     if a.ef == "auto":
         ef = None
-        for e in EF_LADDER:
+        for e in (EF_LADDER if a.config == 1 else EF_LADDER_LARGE):
             recall_by_ef[e] = round(recall_at(e), 5)
             log("%s efSearch %d: true recall@%d = %.4f (%d queries)" % (kind_name, e, n, recall_by_ef[e], nr))
             if recall_by_ef[e] >= a.min_recall:
                 ef = e
                 break
         if ef is None:
-            ef = EF_LADDER[-1]
+            ef = EF_LADDER[-1] if a.config == 1 else EF_LADDER_LARGE[-1]
     else:
         ef = int(a.ef)
         recall_by_ef[ef] = round(recall_at(ef), 5)
@@ -389,7 +446,17 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
             "note": "secondary; the metric's value times one batch at a time"}
     except Exception as e:  # a secondary figure must never cost the bench line
         log("concurrent-batches measurement skipped: %s" % e)
-    if not a.no_cpu_baseline:
+    need_host = 2.3 * 4.0 * d * N + 400.0 * N  # rows twice (generated + the oracle's copy) + both graphs
+    try:
+        avail_host = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1]) * 1024.0
+    except (OSError, StopIteration, ValueError):
+        avail_host = float("inf")
+    if not a.no_cpu_baseline and avail_host < need_host:
+        out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 0, "kind": "port",
+                               "sample": "skipped: the oracle would need %.0f GB of host memory beside the index, %.0f GB "
+                                         "are available" % (need_host / 1e9, avail_host / 1e9)}
+        log("cpu baseline skipped: not enough host memory for a second copy of the index")
+    elif not a.no_cpu_baseline:
         from oracle import oracle_py as O
         t2 = time.time()
         orc = O.OracleHNSW(m, a.ef_cons, d, kind)
@@ -535,6 +602,7 @@ def main():
     # multi-GPU code on a single-GPU box)
     force_dist = os.environ.get("HNSW_BENCH_FORCE_DIST") == "1"
     use_dist = world > 1 or force_dist
+    c.use_dist = use_dist
     if use_dist:
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -637,6 +705,25 @@ def main():
         out.update(result)
         if args.config == 2:
             out["metric"] = "queries/sec, %d x %dd fp32, unit rows, efSearch %d (BASELINE configs[2]; recall@10 reported)" % (N, d, ef)
+        if args.config == 3:
+            out["metric"] = ("queries/sec, %d x %dd fp32 L2, index replicated per GPU, query batch sharded, efSearch %d "
+                             "(BASELINE configs[3]; recall@10 reported)" % (N, d, ef))
+        if getattr(c, "replication", None):
+            out["replication"] = c.replication
+        if getattr(c, "build_info", None):
+            out["index_build"] = c.build_info
+        if args.config == 4:
+            # configs[4] times the BUILD: one "step" is the whole insert_bulk of N points
+            bi = c.build_info
+            out["search_after_build"] = {"queries_per_s": out["value"], "ms_per_step": out["ms_per_step"], "steps": K,
+                                         "warmup": W, "efSearch": ef, "note": "search rate of the index this run built"}
+            out["metric"] = ("points/sec inserted, index build %d x %dd fp32 (BASELINE configs[4]: on-device insert / "
+                             "search_layer, insertion searches sharded over the ranks, RCCL all-gather of the new edges; "
+                             "recall@10 of the built index reported)" % (N, d))
+            out["value"], out["unit"] = bi["points_per_s"], "points/s"
+            out["steps"], out["warmup"], out["ms_per_step"] = 1, 0, round(bi["seconds"] * 1e3, 3)
+            out["scaling"] = "strong"
+            out["config"]["parallelism"] = "every rank holds a replica; insertion searches of each batch split over %d GPU(s)" % world
         if world == 1 and not args.no_extras:
             out.update(extras(c, index, args.kind, ef, local_search))
         # ---- the other vector kind, same run (single GPU only) ---------------------------------------

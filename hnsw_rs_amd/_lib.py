@@ -40,6 +40,11 @@ class QueryStats(C.Structure):
                 ("status", C.c_int32)]
 
 
+class SnapshotDesc(C.Structure):
+    """hnsw_snapshot_desc: the seven flat device arrays of the HBM snapshot + its scalar header"""
+    _fields_ = [("bytes", C.c_uint64 * 7), ("ptr", C.c_void_p * 7), ("header", C.c_uint32 * 32)]
+
+
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
 u64p = C.POINTER(C.c_uint64)
@@ -97,6 +102,9 @@ SYMBOLS = {
     "hnsw_upload": (C.c_int, [vp]),
     "hnsw_device_bytes": (C.c_int, [vp, u64p]),
     "hnsw_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
+    "hnsw_snapshot_describe": (C.c_int, [vp, C.POINTER(SnapshotDesc)]),
+    "hnsw_snapshot_adopt": (C.c_int, [vp, C.POINTER(SnapshotDesc)]),
+    "hnsw_snapshot_commit": (C.c_int, [vp]),
     "hnsw_synth_rows": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, f32p, C.c_uint32]),
     "hnsw_draw_levels": (C.c_int, [C.c_uint32, C.c_uint64, u8p]),
 }

@@ -82,8 +82,21 @@ struct DevBuf {  // RAII device allocation
     }
 };
 
+// a device-only replica (hnsw_snapshot_adopt / _commit) has no host index behind its snapshot
+inline bool is_replica(const hnsw_index *h) { return h->dev.replica; }
+inline uint64_t index_len(const hnsw_index *h) { return is_replica(h) ? h->dev.view.n_points : h->host->len(); }
+int reject_replica(const hnsw_index *h, const char *what) {
+    if (!is_replica(h)) return HNSW_OK;
+    set_error("%s: this handle is a device-only replica (hnsw_snapshot_adopt); it holds no host copy of the index", what);
+    return HNSW_ERR_ARG;
+}
+
 int ensure_uploaded(hnsw_index *h) {
     std::lock_guard<std::mutex> g(h->mu);
+    if (is_replica(h) && !h->dev.valid) {
+        set_error("replica snapshot not committed (hnsw_snapshot_commit)");
+        return HNSW_ERR_ARG;
+    }
     if (!h->dev.current(*h->host)) {
         int rc = h->dev.upload(*h->host, h->device);
         if (rc != HNSW_OK) return rc;
@@ -106,7 +119,7 @@ int check_search_args(const hnsw_index *h, uint32_t ef) {
         set_error("an on-device build on this handle failed half way; the index is incomplete, discard it");
         return HNSW_ERR_ARG;
     }
-    if (h->host->len() == 0) {
+    if (index_len(h) == 0) {
         set_error("index is empty");
         return HNSW_ERR_EMPTY;
     }
@@ -907,6 +920,7 @@ void hnsw_free(hnsw_index *h) { delete h; }
 
 int hnsw_clone(const hnsw_index *h, hnsw_index **out) {
     if (!h || !out) return HNSW_ERR_ARG;
+    if (is_replica(h)) return reject_replica(h, "hnsw_clone");
     hnsw_index *c = new (std::nothrow) hnsw_index();
     if (!c) return HNSW_ERR_OOM;
     c->host.reset(new hx::HostIndex(*h->host));
@@ -919,7 +933,7 @@ int hnsw_get_params(const hnsw_index *h, hnsw_params *out) {
     if (!h || !out) return HNSW_ERR_ARG;
     const hx::Params &p = h->host->params;
     memset(out, 0, sizeof(*out));
-    out->ep = p.ep;
+    out->ep = is_replica(h) ? h->dev.view.ep : p.ep;
     out->vec_kind = (uint32_t)h->host->kind;
     out->m = p.m;
     out->mmax = p.mmax;
@@ -931,6 +945,7 @@ int hnsw_get_params(const hnsw_index *h, hnsw_params *out) {
 }
 
 int hnsw_set_ep(hnsw_index *h, uint32_t ep) {
+    if (h && is_replica(h)) return reject_replica(h, "hnsw_set_ep");
     if (!h || ep >= h->host->len()) {
         set_error("entry point %u out of range", ep);
         return HNSW_ERR_ARG;
@@ -946,6 +961,7 @@ int hnsw_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_t
 int hnsw_insert_bulk_levels(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads,
                             int verbose, const uint8_t *levels) {
     if (!h || !rows) return HNSW_ERR_ARG;
+    if (is_replica(h)) return reject_replica(h, "hnsw_insert_bulk");
     if (h->incomplete_build) return check_search_args(h, 1);
     if (h->gpu_build == 2) return device_build_guard(h, [&] { return gpu_insert_bulk_full(h, rows, n, nb_threads, verbose, levels); });
     if (h->gpu_build) return device_build_guard(h, [&] { return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels); });
@@ -959,6 +975,7 @@ int hnsw_insert_bulk_sharded(hnsw_index *h, const float *rows, uint64_t n, uint3
                              const uint8_t *levels, uint32_t rank, uint32_t world, void *d_send, void *d_recv,
                              uint64_t slot_bytes, hnsw_allgather_fn allgather, void *ctx) {
     if (!h || !rows || world == 0 || rank >= world) return HNSW_ERR_ARG;
+    if (is_replica(h)) return reject_replica(h, "hnsw_insert_bulk_sharded");
     ShardCtx sh{rank, world, static_cast<unsigned char *>(d_send), static_cast<unsigned char *>(d_recv), slot_bytes,
                 allgather, ctx};
     if (h->incomplete_build) return check_search_args(h, 1);
@@ -967,6 +984,7 @@ int hnsw_insert_bulk_sharded(hnsw_index *h, const float *rows, uint64_t n, uint3
 int hnsw_insert_bulk_device(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads,
                             int verbose, const uint8_t *levels) {
     if (!h || !rows) return HNSW_ERR_ARG;
+    if (is_replica(h)) return reject_replica(h, "hnsw_insert_bulk_device");
     if (h->incomplete_build) return check_search_args(h, 1);
     if (h->gpu_build == 1) return device_build_guard(h, [&] { return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels); });
     return device_build_guard(h, [&] { return gpu_insert_bulk_full(h, rows, n, nb_threads, verbose, levels); });
@@ -976,15 +994,19 @@ int hnsw_insert_vec(hnsw_index *h, const float *v, uint32_t *out_id) {
 }
 int hnsw_insert_vec_level(hnsw_index *h, const float *v, int level, uint32_t *out_id) {
     if (!h || !v || level > 255) return HNSW_ERR_ARG;
+    if (is_replica(h)) return reject_replica(h, "hnsw_insert_vec");
+    if (h->incomplete_build) return check_search_args(h, 1);
     return h->host->insert_vec(v, level, out_id);
 }
 int hnsw_import_points(hnsw_index *h, const float *rows, uint64_t n, const uint8_t *levels) {
     if (!h || !rows) return HNSW_ERR_ARG;
+    if (is_replica(h)) return reject_replica(h, "hnsw_import_points");
     return h->host->import_points(rows, n, levels);
 }
 int hnsw_import_layer(hnsw_index *h, uint32_t layer, uint64_t n_nodes, const uint32_t *node_ids,
                       const uint64_t *offsets, const uint32_t *nbrs) {
     if (!h || !node_ids || !offsets) return HNSW_ERR_ARG;
+    if (is_replica(h)) return reject_replica(h, "hnsw_import_layer");
     return h->host->import_layer(layer, n_nodes, node_ids, offsets, nbrs);
 }
 
@@ -1301,7 +1323,7 @@ int hnsw_brute_force_fast(hnsw_index *h, const float *Q, uint64_t nq, uint32_t k
 }
 
 // ---- accessors -----------------------------------------------------------------------------------
-uint64_t hnsw_len(const hnsw_index *h) { return h ? h->host->len() : 0; }
+uint64_t hnsw_len(const hnsw_index *h) { return h ? index_len(h) : 0; }
 
 int hnsw_distance(const hnsw_index *h, uint32_t a, uint32_t b, float *out) {
     if (!h || !out) return HNSW_ERR_ARG;
@@ -1337,7 +1359,10 @@ int hnsw_get_quant(const hnsw_index *h, uint32_t id, uint8_t *codes, float *min_
     return HNSW_OK;
 }
 
-uint32_t hnsw_layer_count(const hnsw_index *h) { return h ? h->host->nb_layers() : 0; }
+uint32_t hnsw_layer_count(const hnsw_index *h) {
+    if (!h) return 0;
+    return is_replica(h) ? h->dev.view.nb_layers : h->host->nb_layers();
+}
 uint64_t hnsw_layer_nb_nodes(const hnsw_index *h, uint32_t layer) {
     return (h && layer < h->host->nb_layers()) ? h->host->layer_nodes[layer].size() : 0;
 }
@@ -1400,6 +1425,11 @@ int hnsw_check_param_compliance(const hnsw_index *h, int *ok) {
 // ---- persistence -----------------------------------------------------------------------------------
 int hnsw_save(const hnsw_index *h, const char *dir) {
     if (!h || !dir) return HNSW_ERR_ARG;
+    if (is_replica(h)) return reject_replica(h, "hnsw_save");
+    if (h->incomplete_build) {  // an index whose on-device build stopped half way must not be written as if it were whole
+        set_error("an on-device build on this handle failed half way; the index is incomplete, not saved");
+        return HNSW_ERR_ARG;
+    }
     return hx::save_index(*h->host, dir);
 }
 int hnsw_load(const char *dir, hnsw_index **out) {
@@ -1425,6 +1455,7 @@ int hnsw_device_count(int *count) {
 int hnsw_set_device(hnsw_index *h, int device) {
     if (!h) return HNSW_ERR_ARG;
     std::lock_guard<std::mutex> g(h->mu);
+    if (is_replica(h) && device != h->device) return reject_replica(h, "hnsw_set_device (a replica stays on the device it was received on)");
     if (device != h->device) h->dev.release();
     h->device = device;
     return HNSW_OK;
@@ -1461,12 +1492,130 @@ int hnsw_set_option(hnsw_index *h, const char *key, int64_t value) {
         set_error("unknown option %s", key);
         return HNSW_ERR_ARG;
     }
-    h->dev.release();  // rebuilt by the next upload
+    if (!is_replica(h)) h->dev.release();  // rebuilt by the next upload
     return HNSW_OK;
 }
 int hnsw_device_bytes(const hnsw_index *h, uint64_t *bytes) {
     if (!h || !bytes) return HNSW_ERR_ARG;
     *bytes = h->dev.valid ? h->dev.bytes : 0;
+    return HNSW_OK;
+}
+
+// ---- snapshot replication ------------------------------------------------------------------------------
+namespace {
+struct SnapHeader {  // what travels in hnsw_snapshot_desc.header (32 words)
+    uint32_t magic, version;
+    int32_t kind;
+    uint32_t dim, n_points, nb_layers, ep, S0, S1, row_stride, half_bytes, nch4, rem;
+    uint32_t fat_stride_lo, fat_stride_hi;
+    uint32_t m, ef_cons;
+    uint32_t reserved[15];
+};
+static_assert(sizeof(SnapHeader) == 32 * 4, "snapshot header is 32 words");
+constexpr uint32_t SNAP_MAGIC = 0x48584E53u;  // "SNXH"
+}  // namespace
+
+int hnsw_snapshot_describe(hnsw_index *h, hnsw_snapshot_desc *out) {
+    if (!h || !out) return HNSW_ERR_ARG;
+    int rc = check_search_args(h, 1);
+    if (rc != HNSW_OK) return rc;
+    if ((rc = ensure_uploaded(h))) return rc;
+    const hx::DevView &v = h->dev.view;
+    memset(out, 0, sizeof(*out));
+    uint64_t nb[7];
+    void *pp[7];
+    h->dev.describe(nb, pp);
+    for (int i = 0; i < HNSW_SNAPSHOT_ARRAYS; i++) {
+        out->bytes[i] = nb[i];
+        out->ptr[i] = pp[i];
+    }
+    SnapHeader hd{};
+    hd.magic = SNAP_MAGIC;
+    hd.version = 1;
+    hd.kind = v.kind;
+    hd.dim = v.dim;
+    hd.n_points = v.n_points;
+    hd.nb_layers = v.nb_layers;
+    hd.ep = v.ep;
+    hd.S0 = v.S0;
+    hd.S1 = v.S1;
+    hd.row_stride = v.row_stride;
+    hd.half_bytes = v.half_bytes;
+    hd.nch4 = v.nch4;
+    hd.rem = v.rem;
+    hd.fat_stride_lo = (uint32_t)v.fat_stride;
+    hd.fat_stride_hi = (uint32_t)(v.fat_stride >> 32);
+    hd.m = (uint32_t)h->host->params.m;
+    hd.ef_cons = (uint32_t)h->host->params.ef_cons;
+    memcpy(out->header, &hd, sizeof(hd));
+    return HNSW_OK;
+}
+
+int hnsw_snapshot_adopt(hnsw_index *h, hnsw_snapshot_desc *d) {
+    if (!h || !d) return HNSW_ERR_ARG;
+    SnapHeader hd;
+    memcpy(&hd, d->header, sizeof(hd));
+    if (hd.magic != SNAP_MAGIC || hd.version != 1) {
+        set_error("hnsw_snapshot_adopt: not a snapshot header");
+        return HNSW_ERR_ARG;
+    }
+    if (h->host->len() != 0 || is_replica(h)) {
+        set_error("hnsw_snapshot_adopt: the receiving handle must be empty (fresh from hnsw_create)");
+        return HNSW_ERR_ARG;
+    }
+    if (hd.kind != h->host->kind || hd.dim != h->host->dim || hd.m != (uint32_t)h->host->params.m) {
+        set_error("hnsw_snapshot_adopt: snapshot of a %ud kind-%d m=%u index offered to a %ud kind-%d m=%u handle", hd.dim,
+                  hd.kind, hd.m, h->host->dim, h->host->kind, (uint32_t)h->host->params.m);
+        return HNSW_ERR_BAD_DIM;
+    }
+    // the sizes must be what the header implies: the kernels index these arrays by id without a range check
+    const uint64_t N = hd.n_points;
+    if (N == 0 || d->bytes[0] != N * hd.row_stride || d->bytes[1] != N * hd.S0 * 4ull || d->bytes[3] != N * 4ull ||
+        d->bytes[2] == 0 || d->bytes[2] % (hd.S1 * 4ull) != 0 || d->bytes[4] < 4 || d->bytes[5] < 4 || hd.ep >= N ||
+        hd.nb_layers == 0) {
+        set_error("hnsw_snapshot_adopt: array sizes do not match the header");
+        return HNSW_ERR_ARG;
+    }
+    std::lock_guard<std::mutex> g(h->mu);
+    uint64_t nb[7];
+    void *pp[7];
+    for (int i = 0; i < 7; i++) nb[i] = d->bytes[i];
+    int rc = h->dev.adopt_alloc(h->device, nb, pp);
+    if (rc != HNSW_OK) {
+        h->dev.release();
+        return rc;
+    }
+    h->device = h->dev.device;
+    for (int i = 0; i < 7; i++) d->ptr[i] = pp[i];
+    hx::DevView v{};
+    v.kind = hd.kind;
+    v.dim = hd.dim;
+    v.n_points = hd.n_points;
+    v.nb_layers = hd.nb_layers;
+    v.ep = hd.ep;
+    v.S0 = hd.S0;
+    v.S1 = hd.S1;
+    v.row_stride = hd.row_stride;
+    v.half_bytes = hd.half_bytes;
+    v.nch4 = hd.nch4;
+    v.rem = hd.rem;
+    v.fat_stride = ((uint64_t)hd.fat_stride_hi << 32) | hd.fat_stride_lo;
+    h->dev.view = v;     // scalars now, pointers at commit
+    h->dev.replica = true;
+    return HNSW_OK;
+}
+
+int hnsw_snapshot_commit(hnsw_index *h) {
+    if (!h) return HNSW_ERR_ARG;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!h->dev.replica || h->dev.valid) {
+        set_error("hnsw_snapshot_commit: no adopted snapshot waiting");
+        return HNSW_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->dev.device));
+    HIP_TRY(hipDeviceSynchronize());  // whatever filled the arrays has finished
+    h->dev.adopt_commit(h->dev.view);
+    h->host->params.ep = h->dev.view.ep;
     return HNSW_OK;
 }
 

@@ -44,7 +44,53 @@ void DeviceIndex::release() {
         if (cur >= 0) (void)hipSetDevice(cur);
     }
     valid = false;
+    replica = false;
     bytes = 0;
+    for (uint64_t &z : sizes_) z = 0;
+}
+
+void DeviceIndex::describe(uint64_t (&nbytes)[7], void *(&ptrs)[7]) const {
+    for (int i = 0; i < 7; i++) {
+        nbytes[i] = bufs_[i] ? sizes_[i] : 0;
+        ptrs[i] = bufs_[i];
+    }
+}
+
+int DeviceIndex::adopt_alloc(int dev, const uint64_t (&nbytes)[7], void *(&ptrs)[7]) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+        set_error("no HIP device available (search runs on the GPU only)");
+        return HNSW_ERR_NO_DEVICE;
+    }
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    release();
+    HIP_TRY(hipSetDevice(dev));
+    device = dev;
+    bytes = 0;
+    for (int i = 0; i < 7; i++) {
+        ptrs[i] = nullptr;
+        if (nbytes[i] == 0) continue;
+        HIP_TRY(hipMalloc(&bufs_[i], nbytes[i]));
+        sizes_[i] = nbytes[i];
+        ptrs[i] = bufs_[i];
+        bytes += nbytes[i];
+    }
+    return HNSW_OK;
+}
+
+void DeviceIndex::adopt_commit(const DevView &scalars) {
+    DevView v = scalars;
+    v.rows = (const uint8_t *)bufs_[0];
+    v.adj0 = (const uint32_t *)bufs_[1];
+    v.adj_up = (const uint32_t *)bufs_[2];
+    v.upper_base = (const uint32_t *)bufs_[3];
+    v.ovf_off = (const uint32_t *)bufs_[4];
+    v.ovf_nbrs = (const uint32_t *)bufs_[5];
+    v.fat = (const uint8_t *)bufs_[6];
+    if (!bufs_[6]) v.fat_stride = 0;
+    view = v;
+    replica = true;
+    valid = true;
 }
 
 template <class F>
@@ -219,6 +265,7 @@ int DeviceIndex::upload(const HostIndex &idx, int dev) {
             HIP_TRY(hipMalloc(&bufs_[i], ups[i].nbytes));
         }
         HIP_TRY(hipMemcpy(bufs_[i], ups[i].src, ups[i].nbytes, hipMemcpyHostToDevice));
+        sizes_[i] = ups[i].nbytes;
         bytes += ups[i].nbytes;
     }
     v.rows = (const uint8_t *)bufs_[0];

@@ -132,13 +132,20 @@ class DeviceIndex {
     int inline_rows = -1;
     uint64_t fat_budget_bytes = 64ull << 30;
     void release();
-    bool current(const HostIndex &idx) const { return valid && version_seen == idx.version; }
+    bool current(const HostIndex &idx) const { return valid && (replica || version_seen == idx.version); }
 
     // mutable views of the adjacency arrays (the on-device build scatters dirty rows into them)
     uint32_t *adj0_mut() { return static_cast<uint32_t *>(bufs_[1]); }
     uint32_t *adj_up_mut() { return static_cast<uint32_t *>(bufs_[2]); }
 
+    // replication (hnsw_snapshot_*): the seven flat arrays of a valid snapshot; an empty DeviceIndex takes
+    // arrays of given sizes (adopt_alloc), the caller fills them, adopt_commit installs the view
+    void describe(uint64_t (&nbytes)[7], void *(&ptrs)[7]) const;
+    int adopt_alloc(int device, const uint64_t (&nbytes)[7], void *(&ptrs)[7]);
+    void adopt_commit(const DevView &scalars);
+
     bool valid = false;
+    bool replica = false;  // adopted from another rank: there is no host index behind it
     int device = -1;
     uint64_t version_seen = 0;
     uint64_t bytes = 0;
@@ -146,6 +153,7 @@ class DeviceIndex {
 
   private:
     void *bufs_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint64_t sizes_[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 
 // row packing helpers shared by upload and tests

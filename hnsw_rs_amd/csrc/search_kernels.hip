@@ -522,9 +522,15 @@ __device__ __forceinline__ float f32_row_sum_staged(const uint4 *src, const floa
 // compile-time constant (all row pieces in flight, dead elements vanish), otherwise the runtime
 // loops of dist_any_dim.  QUANT8: valid on the even lane of the pair; F32: per lane.
 // ---------------------------------------------------------------------------------------------
-template <int KIND, int DS>
-__device__ __forceinline__ float dist_build(const DevView &v, uint32_t id, bool active, int h, const float *yq) {
-    if constexpr (DS > 0 && KIND == HNSW_VEC_QUANT8) {
+// COOP (insert kernel, f32 rows of whole lines): the cooperative gather of coop_rows.inc through ids_s
+// (64 words) and img (4 KiB) -- the insertion searches of a 50-100M point build read rows scattered over
+// tens of GB, where the lane-per-row shape tops out at 1.2 TB/s (profiles/r03_gather_shapes_*.txt).
+template <int KIND, int DS, bool COOP = false>
+__device__ __forceinline__ float dist_build(const DevView &v, uint32_t id, bool active, int h, const float *yq,
+                                            uint32_t *ids_s = nullptr, unsigned char *img = nullptr, int lane = 0) {
+    if constexpr (COOP && coop_rows<KIND, DS>()) {
+        return __builtin_sqrtf(f32_rows_coop<(DS > 0 ? DS : 32), HX_COOP_K>(v.rows, id, active, yq, ids_s, img, lane));
+    } else if constexpr (DS > 0 && KIND == HNSW_VEC_QUANT8) {
         constexpr int NQ = 4 * (DS / 8) + DS % 8;  // elements of half 0 (half 1 has DS % 8 fewer)
         constexpr int P = (8 + NQ + 15) / 16;
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1910,6 +1916,11 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
         ((KIND == HNSW_VEC_QUANT8 ? 2u * (v.half_bytes - 8) * 4u : v.dim * 4u) + 15u) & ~15u;
     float *yq = reinterpret_cast<float *>(selk + 64);
     float *yqe = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(yq) + yq_bytes);
+    // cooperative row gather (f32 rows of whole lines): the stage image lives in perm (4 KiB, used by the
+    // merges only, never during a distance pass), the rank -> id words behind the staged rows
+    unsigned char *coop_img = reinterpret_cast<unsigned char *>(perm);
+    uint32_t *coop_ids = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(yqe) + yq_bytes);
+    static_assert(!coop_rows<KIND, DS>() || 64 * R * 8 >= (int)HX_COOP_IMG_BYTES, "perm holds the stage image");
 
     constexpr int LPC = (KIND == HNSW_VEC_QUANT8) ? 2 : 1;
     constexpr int CHUNK = 64 / LPC;
@@ -1949,7 +1960,7 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
         const u64 fm = __ballot(fresh && first);
         if (visit) n_vis += (uint32_t)__popcll(fm);  // what the table really holds
         if (fm == 0) return;
-        const float dist = dist_build<KIND, DS>(v, id, fresh, h, yq);
+        const float dist = dist_build<KIND, DS, true>(v, id, fresh, h, yq, coop_ids, coop_img, lane);
         u64 key = KEY_INVALID;
         bool nan = false;
         if (fresh && first) {
@@ -2091,7 +2102,7 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
                     const uint32_t cdb = (uint32_t)__shfl((int)my_db, src);
                     const bool act = __shfl(open ? 1 : 0, src) != 0;
                     if (__ballot(act) == 0) continue;
-                    const float dist = dist_build<KIND, DS>(v, cid, act, h, yqe);
+                    const float dist = dist_build<KIND, DS, true>(v, cid, act, h, yqe, coop_ids, coop_img, lane);
                     bool rej = false;
                     if (act && first) {
                         if (dist != dist) status = HNSW_ERR_NAN_INPUT;
@@ -2220,7 +2231,7 @@ int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipSt
     const uint32_t slots_log2 = 12 + (a.ef_cons > 64 ? 1 : 0) + (a.ef_cons > 160 ? 1 : 0);
     const size_t yq_bytes =
         ((v.kind == HNSW_VEC_QUANT8 ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4) + 15) & ~15ull;
-    const size_t lds = (4ull << slots_log2) + 64ull * HX_MAX_R * 8 + 64 * 8 + 2 * yq_bytes;
+    const size_t lds = (4ull << slots_log2) + 64ull * HX_MAX_R * 8 + 64 * 8 + 2 * yq_bytes + 256 /* rank -> id words */;
     if (lds > 160 * 1024) {
         set_error("insert kernel needs %zu bytes of LDS", lds);
         return HNSW_ERR_ARG;
@@ -2234,9 +2245,11 @@ int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipSt
               : v.dim == 768 ? hx_insert_kernel<HNSW_VEC_QUANT8, 768>
                              : hx_insert_kernel<HNSW_VEC_QUANT8, 0>;
     else
-        kfn = v.dim == 100   ? hx_insert_kernel<HNSW_VEC_F32, 100>
-              : v.dim == 128 ? hx_insert_kernel<HNSW_VEC_F32, 128>
-                             : hx_insert_kernel<HNSW_VEC_F32, 0>;
+        kfn = v.dim == 100                           ? hx_insert_kernel<HNSW_VEC_F32, 100>
+              : v.dim == 128                         ? hx_insert_kernel<HNSW_VEC_F32, 128>
+              : v.dim == 256 && v.row_stride == 1024 ? hx_insert_kernel<HNSW_VEC_F32, 256>  // the configs[4] dimension
+              : v.dim == 768 && v.row_stride == 3072 ? hx_insert_kernel<HNSW_VEC_F32, 768>  // the configs[2] dimension
+                                                     : hx_insert_kernel<HNSW_VEC_F32, 0>;
     const void *kern = reinterpret_cast<const void *>(kfn);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -374,6 +374,68 @@ class HNSW:
         check(self._L.hnsw_device_bytes(self._h, C.byref(b)))
         return b.value
 
+    # ---- replication over the GPUs of a node ------------------------------------
+    @staticmethod
+    def replicate(index, m, ef_cons, dim, vec_kind, group=None, src=0, device=None, chunk_bytes=1 << 30):
+        """Every rank of the torch.distributed group calls this; `index` is the built index on rank `src`
+        (ignored elsewhere).  The snapshot's flat HBM arrays are broadcast from `src` -- RCCL over xGMI when
+        the group's backend is nccl, staged through the host for gloo (the CPU tests) -- and every other
+        rank gets a device-only replica that answers searches (hnsw_snapshot_describe / _adopt / _commit).
+        Returns the source's own index on `src`, the replica elsewhere.  Arrays travel in pieces of at most
+        chunk_bytes: a 51-GB row table is not one collective."""
+        import torch
+        import torch.distributed as dist
+        from ._lib import SnapshotDesc
+        rank = dist.get_rank(group)
+        on_device = dist.get_backend(group) == "nccl"
+        dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        L = _lib.lib()
+        desc = SnapshotDesc()
+        if rank == src:
+            index.set_device(dev.index if dev.index is not None else 0)
+            check(L.hnsw_snapshot_describe(index._h, C.byref(desc)))
+            out = index
+        else:
+            out = HNSW.new(m, ef_cons, dim, vec_kind)
+            out.set_device(dev.index if dev.index is not None else 0)
+        # sizes + header: 7 + 32 words, one small broadcast
+        meta = torch.zeros(7 + 32, dtype=torch.int64)
+        if rank == src:
+            meta[:7] = torch.tensor([int(desc.bytes[i]) for i in range(7)], dtype=torch.int64)
+            meta[7:] = torch.tensor([int(desc.header[i]) for i in range(32)], dtype=torch.int64)
+        meta = meta.to(dev) if on_device else meta
+        dist.broadcast(meta, src=src, group=group)
+        meta = meta.cpu()
+        if rank != src:
+            for i in range(7):
+                desc.bytes[i] = int(meta[i])
+            for i in range(32):
+                desc.header[i] = int(meta[7 + i])
+            check(L.hnsw_snapshot_adopt(out._h, C.byref(desc)))
+
+        class _Mem:  # a view of library-owned device memory for torch (CUDA array interface)
+            def __init__(self, ptr, nbytes):
+                self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+        for i in range(7):
+            nbytes = int(desc.bytes[i])
+            if nbytes == 0:
+                continue
+            whole = torch.as_tensor(_Mem(int(desc.ptr[i]), nbytes), device=dev)
+            for lo in range(0, nbytes, chunk_bytes):
+                piece = whole[lo:min(nbytes, lo + chunk_bytes)]
+                if on_device:
+                    dist.broadcast(piece, src=src, group=group)
+                else:
+                    host = piece.cpu() if rank == src else torch.empty(piece.shape[0], dtype=torch.uint8)
+                    dist.broadcast(host, src=src, group=group)
+                    if rank != src:
+                        piece.copy_(host)
+        torch.cuda.synchronize(dev)
+        if rank != src:
+            check(L.hnsw_snapshot_commit(out._h))
+        return out
+
 
 def synth_rows(recipe, seed, first_row, n, d, nb_threads=8):
     out = np.zeros((n, d), dtype=np.float32)

@@ -245,6 +245,29 @@ int hnsw_device_bytes(const hnsw_index *h, uint64_t *bytes);
  *                      (recall@10 + 0.0006 on the bench's index) for ~0.3 s more per 1M points */
 int hnsw_set_option(hnsw_index *h, const char *key, int64_t value);
 
+/* ---- replication of the HBM snapshot over the GPUs of a node ----------------------------------- */
+/* The search path replicates the index per GPU (the reference keeps one index in
+ * one process's RAM, template.rs:35-40).  The snapshot is a handful of flat device arrays plus a small
+ * scalar header, so a replica is made by broadcasting them -- the caller's collective (ncclBroadcast over
+ * xGMI; torch.distributed in hnsw_rs_amd/hnsw.py), the library only names the buffers:
+ *   source rank:       hnsw_snapshot_describe(h, &d)   uploads if needed; d.bytes / d.ptr / d.header
+ *   every other rank:  hnsw_create(same m, ef_cons, dim, kind), receive d.bytes and d.header,
+ *                      hnsw_snapshot_adopt(h, &d)      allocates the arrays on the handle's device, fills d.ptr
+ *                      <broadcast every array into d.ptr[i]>
+ *                      hnsw_snapshot_commit(h)         the handle now answers searches
+ * A handle made this way is a DEVICE-ONLY replica: it serves the search, brute-force and test-seam entry
+ * points; it holds no host copy, so insert_*, save and the per-point / per-layer accessors fail with
+ * HNSW_ERR_ARG (hnsw_len, hnsw_layer_count and hnsw_get_params answer from the header). */
+#define HNSW_SNAPSHOT_ARRAYS 7
+typedef struct hnsw_snapshot_desc {
+    uint64_t bytes[HNSW_SNAPSHOT_ARRAYS]; /* size of each array, 0 = absent */
+    void *ptr[HNSW_SNAPSHOT_ARRAYS];      /* device pointers on this handle's device */
+    uint32_t header[32];                  /* scalar part, opaque: broadcast it verbatim */
+} hnsw_snapshot_desc;
+int hnsw_snapshot_describe(hnsw_index *h, hnsw_snapshot_desc *out);
+int hnsw_snapshot_adopt(hnsw_index *h, hnsw_snapshot_desc *inout);
+int hnsw_snapshot_commit(hnsw_index *h);
+
 /* ---- harness helpers (not part of the reference's API) --------------------------------------- */
 /* Synthetic "GloVe-shaped" data, counter-based so any row can be generated independently:
  * recipe 0 = low intrinsic dimension clusters (A), 1 = isotropic mixture (B), 2 = U[0,1)

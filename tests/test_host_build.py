@@ -185,3 +185,22 @@ def test_glove_text_loader_matches_the_binary_fixture(testdata, tmp_path):
         f.write("odd 1.0 2.0\n")
     with pytest.raises(ValueError):
         load_glove_array(0, path)
+
+
+def test_snapshot_replication_argument_checks_without_a_device():
+    """hnsw_snapshot_describe / _adopt / _commit refuse what they cannot serve before
+    they touch a device"""
+    import ctypes as C
+    from hnsw_rs_amd import _lib
+    L = _lib.lib()
+    idx = H.HNSW.new(8, None, 10)
+    desc = _lib.SnapshotDesc()
+    assert L.hnsw_snapshot_describe(idx._h, C.byref(desc)) == _lib.ERR_EMPTY   # nothing to replicate yet
+    assert L.hnsw_snapshot_commit(idx._h) == _lib.ERR_ARG                       # nothing adopted
+    assert L.hnsw_snapshot_adopt(idx._h, C.byref(desc)) == _lib.ERR_ARG         # all-zero header: not a snapshot
+    assert b"not a snapshot header" in L.hnsw_last_error()
+    full = H.HNSW.new(8, None, 10).insert_bulk(rand_vectors(50, 10, 3), 1, False)
+    desc.header[0] = 0x48584E53
+    desc.header[1] = 1
+    assert L.hnsw_snapshot_adopt(full._h, C.byref(desc)) == _lib.ERR_ARG        # receiver must be empty
+    assert b"must be empty" in L.hnsw_last_error()
