@@ -123,8 +123,10 @@ int check_search_args(const hnsw_index *h, uint32_t ef) {
         set_error("index is empty");
         return HNSW_ERR_EMPTY;
     }
-    if (ef > 64 * 16) {
-        set_error("ef = %u is above the supported maximum of 1024", ef);
+    // no limit on ef (template.rs:306-311): up to 1024 the list lives in a wave's registers, beyond that in HBM
+    // scratch (hx_search_spill_kernel: exact, slow).  2^26 entries only bounds the scratch arithmetic.
+    if (ef > (1u << 26)) {
+        set_error("ef = %u is above 2^26", ef);
         return HNSW_ERR_ARG;
     }
     return HNSW_OK;
@@ -1027,7 +1029,7 @@ int hnsw_search_batch(hnsw_index *h, const float *Q, uint64_t nq, uint32_t n, ui
         return HNSW_OK;
     }
     hx::DevView dummy{};
-    dummy.nb_layers = h->host->nb_layers();
+    dummy.nb_layers = hnsw_layer_count(h);  // the host index's, or the adopted snapshot's for a replica
     hx::SearchArgs a = ann_args(dummy, nullptr, n, ef, nullptr, nullptr, nullptr, nullptr);
     return search_host(h, a, Q, nq, ids, dists, counts, stats, nullptr);
 }
@@ -1131,7 +1133,8 @@ int hnsw_search_layer(hnsw_index *h, uint32_t layer, const float *q, const uint3
     int rc = check_search_args(h, ef);
     if (rc != HNSW_OK) return rc;
     if (!q || !entry_ids || !out_ids || !out_count || n_entry == 0 || ef == 0) return HNSW_ERR_ARG;
-    if (layer >= h->host->nb_layers()) {
+    if (is_replica(h)) return reject_replica(h, "hnsw_search_layer (the seam checks its entry set against the host graph)");
+    if (layer >= hnsw_layer_count(h)) {
         set_error("Layer %u not found in the structure.", layer);  // layers.rs:25-30 panics
         return HNSW_ERR_ARG;
     }

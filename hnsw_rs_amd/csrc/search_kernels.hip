@@ -2497,10 +2497,14 @@ uint32_t default_slots_log2(uint32_t ef, uint32_t s0) {
     if (e <= 112) return 12;  // 4096 slots, 16 KiB: limit 3072
     if (e <= 256) return 13;  // 8192 slots, 32 KiB: limit 6144
     if (e <= 576) return 14;  // 64 KiB: limit 12288
-    return 15;                // 128 KiB
+    if (ef <= 64 * HX_MAX_R_WIDE) return 15;  // 128 KiB
+    // the HBM-resident table of hx_search_spill_kernel (limit: one half): about 30 visited ids per list entry
+    uint32_t l = 16;
+    while (l < 30 && (1ull << l) < 64ull * e) l++;
+    return l;
 }
 uint32_t default_slots_log2(uint32_t ef) { return default_slots_log2(ef, 32); }
-uint32_t max_slots_log2(uint32_t) { return 15; }
+uint32_t max_slots_log2(uint32_t ef) { return ef <= 64 * HX_MAX_R_WIDE ? 15 : 31; }  // (the spill kernel caps its table at 4 N slots)
 
 template <int KIND, int P, int DS, int R, bool FAT>
 static int launch_one(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint32_t slots_log2,
@@ -2618,6 +2622,322 @@ static int launch_r(const DevView &v, const SearchArgs &a, uint32_t nblocks, uin
     return HNSW_ERR_ARG;
 }
 
+
+// =============================================================================================
+// ef beyond what a wave's registers hold (> 1024).  The reference's ann_by_vector has no limit on ef
+// (template.rs:306-311: `selected` is a BTreeSet); the register-resident list of the kernels above stops
+// at sixteen registers per lane.  This kernel keeps the SAME single sorted list (key = dist_bits << 32 |
+// id, bit 63 = expanded) and the visited set in HBM scratch instead, one wave per query, and applies a
+// batch of neighbour distances the way the reference literally does -- one element at a time
+// (searcher.rs:74-94): position by a wave-wide count, the tail moved up by one from the top, the element
+// stored.  Slow (every insertion is a few dependent HBM round trips) but exact and without a limit other
+// than memory: the list holds ef entries of 8 bytes, the table a power of two of slots that the host
+// doubles and re-runs when a query fills it to one half (HNSW_ERR_OVERFLOW), which ends at 4 N slots.
+// List and table are read and written through L2 (agent-scope relaxed atomics: the lanes of the wave
+// hand entries to each other through memory, and the table's compare-and-swap executes there).
+// =============================================================================================
+struct SpillScratch {
+    u64 *lists;        // nblocks x list_cap
+    uint32_t *tabs;    // nblocks << tab_log2
+    uint32_t list_cap;
+    uint32_t tab_log2;
+    uint32_t q_first;  // launch block b serves query (selection entry) q_first + b
+};
+
+__device__ __forceinline__ uint32_t spill_ld(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 spill_ld(const u64 *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void spill_st(u64 *p, u64 x) {
+    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void spill_st(uint32_t *p, uint32_t x) {
+    __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a wave's own stores have reached L2 before its next loads are issued
+__device__ __forceinline__ void spill_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// IntSet::insert on the HBM table (linear probing, load <= 1/2): true when id was absent
+__device__ __forceinline__ bool spill_visited_insert(uint32_t *tab, uint32_t mask, uint32_t shift, uint32_t id) {
+    uint32_t s = ((id * 0x9E3779B1u) >> shift) & mask;
+    while (true) {
+        const uint32_t cur = spill_ld(tab + s);
+        if (cur == id) return false;
+        if (cur == HX_EMPTY_SLOT) {
+            const uint32_t old = atomicCAS(tab + s, HX_EMPTY_SLOT, id);
+            if (old == HX_EMPTY_SLOT) return true;
+            if (old == id) return false;
+        }
+        s = (s + 1) & mask;  // taken (by another id, possibly of this very pass): next slot
+    }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(64)
+hx_search_spill_kernel(const DevView v, const SearchArgs a, const SpillScratch sp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *yq = reinterpret_cast<float *>(smem);
+    const int lane = threadIdx.x;
+    const uint32_t qi = sp.q_first + blockIdx.x;
+    const uint32_t q = a.qsel ? a.qsel[qi] : qi;
+    u64 *L = sp.lists + (size_t)blockIdx.x * sp.list_cap;
+    uint32_t *tab_all = sp.tabs + ((size_t)blockIdx.x << sp.tab_log2);
+    constexpr int LPC = (KIND == HNSW_VEC_QUANT8) ? 2 : 1;
+    constexpr int CHUNK = 64 / LPC;
+    const int h = (LPC == 2) ? (lane & 1) : 0;
+    const int cslot = lane / LPC;
+    const uint32_t d = v.dim;
+    uint32_t n_dist = 0, n_exp = 0, sum_deg = 0;
+    int32_t status = HNSW_OK;
+    if (!stage_query<KIND>(v, a.Q + (size_t)q * d, yq, lane)) status = HNSW_ERR_NAN_INPUT;
+
+    uint32_t n_cur = 0, hint = 0, n_vis = 0;  // hint: every entry before it is expanded
+    u64 last_key = KEY_INVALID;                // key of the last entry once the list holds ef of them
+    uint32_t tmask = 0, tshift = 0, vis_limit = 0;
+
+    // `selected.insert(e)` + `pop_last` when over ef (searcher.rs:77-92), e wave-uniform
+    auto insert_one = [&](u64 e, uint32_t ef_l) __attribute__((always_inline)) {
+        if (n_cur >= ef_l && !(e < last_key)) return;
+        uint32_t pos = 0;
+        for (uint32_t i = 0; i < n_cur; i += 64) {  // entries below e: the list is sorted, the first chunk that holds a larger one ends the count
+            const uint32_t idx = i + (uint32_t)lane;
+            const u64 k = idx < n_cur ? (spill_ld(L + idx) & KEY_MASK) : KEY_INVALID;
+            const u64 below = __ballot(k < e);
+            pos += (uint32_t)__popcll(below);
+            if (below != ~0ull) break;
+        }
+        const uint32_t n_new = n_cur < ef_l ? n_cur + 1 : n_cur;  // full: the last entry falls off
+        for (uint32_t hi = n_new; hi > pos + 1;) {                // entries pos .. n_new - 2 move up by one, top chunk first
+            const bool mv = hi >= 1u + (uint32_t)lane && hi - 1u - (uint32_t)lane > pos;
+            const uint32_t idx = hi - 1u - (uint32_t)lane;
+            u64 t = 0;
+            if (mv) t = spill_ld(L + idx - 1);
+            if (mv) spill_st(L + idx, t);  // the chunk's loads have returned before its stores issue
+            if (hi <= 64) break;
+            hi -= 64;
+        }
+        if (lane == 0) spill_st(L + pos, e);
+        spill_fence();
+        n_cur = n_new;
+        if (pos < hint) hint = pos;
+        last_key = n_cur >= ef_l ? (readlane64(spill_ld(L + (n_cur - 1)), 0) & KEY_MASK) : KEY_INVALID;
+    };
+    // one pass over up to CHUNK ids: visited filter, distance, then the batch applied in lane order
+    auto process = [&](uint32_t id, bool valid, bool visit, uint32_t ef_l) __attribute__((always_inline)) {
+        bool fresh = valid;
+        if (visit) {
+            bool f = false;
+            if (valid && h == 0) f = spill_visited_insert(tab_all, tmask, tshift, id);
+            if (LPC == 2) f = (pair_swap_i(f ? 1 : 0) | (f ? 1 : 0)) != 0;
+            fresh = f;
+        }
+        const u64 fm = __ballot(fresh && h == 0);
+        if (visit) n_vis += (uint32_t)__popcll(fm);
+        if (fm == 0) return;
+        n_dist += (uint32_t)__popcll(fm);
+        const float dist = dist_any_dim<KIND>(v, id, fresh, h, yq);
+        const bool mine = fresh && h == 0;
+        if (__ballot(mine && dist != dist)) {
+            status = HNSW_ERR_NAN_INPUT;  // Dist::cmp would panic (dist.rs:32)
+            return;
+        }
+        const u64 key = mine ? (((u64)__builtin_bit_cast(uint32_t, dist) << 32) | id) : KEY_INVALID;
+        u64 it = __ballot(mine);
+        while (it) {
+            const int j = __ffsll((long long)it) - 1;
+            it &= it - 1;
+            insert_one(readlane64(key, j), ef_l);
+        }
+    };
+
+    // the table of a layer: all of it for a wide list, 4096 slots of it for the greedy upper layers
+    auto use_table = [&](uint32_t ef_l) __attribute__((always_inline)) {
+        const uint32_t log2 = ef_l <= 64 ? min(sp.tab_log2, 12u) : sp.tab_log2;
+        tmask = (1u << log2) - 1;
+        tshift = 32 - log2;
+        vis_limit = 1u << (log2 - 1);
+        for (uint32_t s2 = lane; s2 <= tmask; s2 += 64) spill_st(tab_all + s2, HX_EMPTY_SLOT);
+        spill_fence();
+    };
+
+    if (status == HNSW_OK) {
+        // ---- entry set: {ep} (template.rs:316-319) or the caller's (search_layer seam) ----
+        const uint32_t n_entry = a.entries ? a.n_entry : 1;
+        const uint32_t ef_first = max(1u, (a.layer_hi > a.layer_lo) ? a.ef_upper : a.ef_bottom);
+        for (uint32_t base = 0; base < n_entry; base += CHUNK) {
+            const uint32_t i = base + cslot;
+            const bool valid = i < n_entry;
+            uint32_t id = 0;
+            if (valid) id = a.entries ? a.entries[i] : v.ep;
+            if (__ballot(valid && id >= v.n_points)) {
+                status = HNSW_ERR_ARG;
+                break;
+            }
+            process(id, valid, false, max(ef_first, n_entry));
+        }
+    }
+    for (int layer = a.layer_hi; status == HNSW_OK && layer >= a.layer_lo; layer--) {
+        const uint32_t ef_l = max(1u, layer > a.layer_lo ? a.ef_upper : a.ef_bottom);
+        use_table(ef_l);
+        // candidates ∪= selected, visited ∪= ids(selected)  (searcher.rs:32-33)
+        for (uint32_t i = 0; i < n_cur; i += 64) {
+            const uint32_t idx = i + (uint32_t)lane;
+            if (idx < n_cur) {
+                const u64 k = spill_ld(L + idx) & KEY_MASK;
+                spill_st(L + idx, k);
+                spill_visited_insert(tab_all, tmask, tshift, (uint32_t)k);
+            }
+        }
+        spill_fence();
+        n_vis = n_cur;
+        hint = 0;
+        last_key = n_cur >= ef_l ? (readlane64(spill_ld(L + (n_cur - 1)), 0) & KEY_MASK) : KEY_INVALID;
+        const uint32_t S = layer == 0 ? v.S0 : v.S1;
+        while (status == HNSW_OK) {
+            // ---- candidates.pop_first(): the smallest entry not expanded yet (searcher.rs:35-44) ----
+            int pos = -1;
+            u64 ck = 0;
+            for (uint32_t i = hint; i < n_cur; i += 64) {
+                const uint32_t idx = i + (uint32_t)lane;
+                const u64 k = idx < n_cur ? spill_ld(L + idx) : KEY_INVALID;
+                const u64 un = __ballot((k >> 63) == 0);
+                if (un) {
+                    const int j = __ffsll((long long)un) - 1;
+                    pos = (int)i + j;
+                    ck = readlane64(k, j);
+                    break;
+                }
+            }
+            if (pos < 0) break;
+            if (lane == 0) spill_st(L + pos, ck | KEY_EXPANDED);
+            spill_fence();
+            hint = (uint32_t)pos + 1;
+            const uint32_t cid = (uint32_t)ck;
+            n_exp++;
+            const uint32_t *row;
+            if (layer == 0) {
+                row = v.adj0 + (size_t)cid * S;
+            } else {
+                const uint32_t ub = v.upper_base[cid];
+                if (ub == HX_EMPTY_SLOT) {  // Graph::neighbors_vec -> NodeNotInGraph
+                    status = HNSW_ERR_NODE_NOT_IN_GRAPH;
+                    break;
+                }
+                row = v.adj_up + ((size_t)ub + layer - 1) * S;
+            }
+            uint32_t ovf = HX_EMPTY_SLOT;
+            for (uint32_t c0 = 0; c0 < S && status == HNSW_OK; c0 += CHUNK) {
+                const uint32_t slot = c0 + cslot;
+                uint32_t nb = HX_EMPTY_SLOT;
+                if (slot < S) nb = row[slot];
+                const bool is_ptr = nb != HX_EMPTY_SLOT && (nb & HX_OVF_FLAG);
+                const bool valid = nb != HX_EMPTY_SLOT && !is_ptr;
+                const u64 pm = __ballot(is_ptr);
+                if (pm) ovf = (uint32_t)__builtin_amdgcn_readlane((int)nb, __ffsll((long long)pm) - 1) & ~HX_OVF_FLAG;
+                const uint32_t cnt = (uint32_t)__popcll(__ballot(valid && h == 0));
+                if (cnt == 0) continue;
+                sum_deg += cnt;
+                if (n_vis + cnt > vis_limit) {
+                    status = HNSW_ERR_OVERFLOW;
+                    break;
+                }
+                process(nb, valid, true, ef_l);
+            }
+            if (status == HNSW_OK && ovf != HX_EMPTY_SLOT) {  // degree > S: the rest of the row
+                const uint32_t lo = v.ovf_off[ovf], hi = v.ovf_off[ovf + 1];
+                for (uint32_t base = lo; base < hi && status == HNSW_OK; base += CHUNK) {
+                    const uint32_t i = base + cslot;
+                    const bool valid = i < hi;
+                    const uint32_t nb = valid ? v.ovf_nbrs[i] : HX_EMPTY_SLOT;
+                    const uint32_t cnt = (uint32_t)__popcll(__ballot(valid && h == 0));
+                    sum_deg += cnt;
+                    if (n_vis + cnt > vis_limit) {
+                        status = HNSW_ERR_OVERFLOW;
+                        break;
+                    }
+                    process(nb, valid, true, ef_l);
+                }
+            }
+        }
+    }
+
+    // ---- get_top_selected(n) (results.rs:59-61) ----
+    const uint32_t count = status == HNSW_OK ? min(a.n, n_cur) : 0;
+    for (uint32_t idx = lane; idx < a.n; idx += 64) {
+        const bool have = idx < count;
+        const u64 k = have ? spill_ld(L + idx) : KEY_INVALID;
+        a.out_ids[(size_t)q * a.n + idx] = have ? (uint32_t)k : HX_EMPTY_SLOT;
+        if (a.out_dists)
+            a.out_dists[(size_t)q * a.n + idx] =
+                have ? __builtin_bit_cast(float, (uint32_t)((k & KEY_MASK) >> 32)) : __builtin_inff();
+    }
+    if (lane == 0) {
+        if (a.out_counts) a.out_counts[q] = count;
+        hnsw_query_stats st;
+        st.n_dist = n_dist;
+        st.n_exp = n_exp;
+        st.sum_deg = sum_deg;
+        st.status = status;
+        a.out_stats[q] = st;
+    }
+}
+
+static int launch_spill(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint32_t slots_log2,
+                        hipStream_t stream, uint32_t ef_max) {
+    // table: what the caller asks for (it doubles on HNSW_ERR_OVERFLOW), never more than 4 N slots -- a
+    // layer visits every id at most once, so a table of 4 N cannot fill to its limit of one half
+    uint32_t cap_log2 = 12;
+    while (cap_log2 < 31 && (1ull << cap_log2) < 4ull * v.n_points) cap_log2++;
+    const uint32_t tab_log2 = std::min(std::max(slots_log2, 12u), cap_log2);
+    const uint64_t list_cap = ef_max;
+    const uint64_t per_q = list_cap * 8 + (4ull << tab_log2);
+    const uint64_t budget = 1ull << 30;  // scratch per launch
+    const uint32_t group = (uint32_t)std::min<uint64_t>(nblocks, std::max<uint64_t>(1, budget / per_q));
+    const size_t yq_bytes =
+        ((v.kind == HNSW_VEC_QUANT8 ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4) + 15) & ~15ull;
+    for (uint32_t first = 0; first < nblocks; first += group) {
+        const uint32_t n = std::min(group, nblocks - first);
+        void *mem = nullptr;
+        bool async = true;
+        if (hipMallocAsync(&mem, n * per_q, stream) != hipSuccess) {  // no stream-ordered pool: plain allocation
+            (void)hipGetLastError();
+            async = false;
+            hipError_t e = hipMalloc(&mem, n * per_q);
+            if (e != hipSuccess) {
+                set_error("search with ef = %u needs %llu bytes of scratch: %s", ef_max, (unsigned long long)(n * per_q),
+                          hipGetErrorString(e));
+                return HNSW_ERR_OOM;
+            }
+        }
+        SpillScratch sp{};
+        sp.lists = static_cast<u64 *>(mem);
+        sp.tabs = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(mem) + (size_t)n * list_cap * 8);
+        sp.list_cap = (uint32_t)list_cap;
+        sp.tab_log2 = tab_log2;
+        sp.q_first = first;
+        if (v.kind == HNSW_VEC_QUANT8)
+            hipLaunchKernelGGL(hx_search_spill_kernel<HNSW_VEC_QUANT8>, dim3(n), dim3(64), yq_bytes, stream, v, a, sp);
+        else
+            hipLaunchKernelGGL(hx_search_spill_kernel<HNSW_VEC_F32>, dim3(n), dim3(64), yq_bytes, stream, v, a, sp);
+        hipError_t e = hipGetLastError();
+        if (async) {
+            (void)hipFreeAsync(mem, stream);
+        } else {
+            (void)hipStreamSynchronize(stream);
+            (void)hipFree(mem);
+        }
+        if (e != hipSuccess) {
+            set_error("search kernel launch (ef = %u): %s", ef_max, hipGetErrorString(e));
+            return HNSW_ERR_HIP;
+        }
+    }
+    return HNSW_OK;
+}
+
 int launch_search(const DevView &v, const SearchArgs &a_in, uint32_t nblocks, uint32_t slots_log2,
                   hipStream_t stream) {
     if (nblocks == 0) return HNSW_OK;
@@ -2633,10 +2953,8 @@ int launch_search(const DevView &v, const SearchArgs &a_in, uint32_t nblocks, ui
         // beyond 512 entries: the any-dimension kernel with sixteen list registers per lane (ef <= 1024;
         // one wave per CU: the visited table takes 128 KiB).  The reference has no limit
         // (template.rs:306-311); this is as far as a wave-resident list goes.
-        if (ef_max > 64 * HX_MAX_R_WIDE) {
-            set_error("ef = %u is above the supported maximum of %d", ef_max, 64 * HX_MAX_R_WIDE);
-            return HNSW_ERR_ARG;
-        }
+        // beyond 1024: list and visited table in HBM scratch, exact and slow (the reference has no limit)
+        if (ef_max > 64 * HX_MAX_R_WIDE) return launch_spill(v, a, nblocks, slots_log2, stream, ef_max);
         if (v.kind == HNSW_VEC_QUANT8)
             return launch_one<HNSW_VEC_QUANT8, 0, 0, HX_MAX_R_WIDE, false>(v, a, nblocks, slots_log2, stream);
         return launch_one<HNSW_VEC_F32, 0, 0, HX_MAX_R_WIDE, false>(v, a, nblocks, slots_log2, stream);

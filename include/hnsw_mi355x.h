@@ -145,7 +145,9 @@ int hnsw_import_layer(hnsw_index *h, uint32_t layer, uint64_t n_nodes, const uin
 /* ---- query (the hot path; HIP kernels) ------------------------------------------------------ */
 /* HNSW::ann_by_vector(&self, &Vec<f32>, n, ef) -> Result<Vec<NodeID>, String>, template.rs:306-335.
  * ids[n]; *count = number of ids returned (< n when ef < n or the index is tiny).
- * ef <= 1024 (HNSW_ERR_ARG above: the candidate list lives in one wave's registers; the reference has no limit). */
+ * No limit on ef, like the reference: up to 1024 the candidate list lives in one wave's registers; beyond that
+ * list and visited set live in HBM scratch (hx_search_spill_kernel: the same results, one insertion at a time,
+ * orders of magnitude slower -- meant for correctness at the reference's contract, not for throughput). */
 int hnsw_search(hnsw_index *h, const float *q, uint32_t n, uint32_t ef, uint32_t *ids,
                 uint32_t *count);
 /* Batched form (new; the reference answers one query per call): Q is nq x dim host memory,

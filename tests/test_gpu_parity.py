@@ -98,14 +98,39 @@ def test_dimensions_and_vector_kinds(kind, d):
 @pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
 @pytest.mark.parametrize("ef", [65, 128, 200, 300, 512, 513, 700, 1024])
 def test_large_ef_uses_wider_lists(ef, kind):
-    """two, four, eight list registers per lane; beyond 512 the any-dimension kernel with sixteen (ef <= 1024);
-    above that an error (the reference has no limit, template.rs:306-311: a documented limit here)"""
+    """two, four, eight list registers per lane; beyond 512 the any-dimension kernel with sixteen (ef <= 1024)"""
     n, d, m = 3000, 24, 16
     vs, qs = rand_vectors(n, d, 1), rand_vectors(32, d, 2)
     index, orc = both(vs, O.draw_levels(n, m, 9), m, kind=kind, threads=4)
     assert_search_equal(index.search_batch(qs, 100, ef), orc.search_batch(qs, 100, ef), "ef=%d" % ef)
-    with pytest.raises(H.HnswError):
-        index.search_batch(qs, 10, 1025)
+
+
+@pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
+def test_ef_beyond_the_register_list_is_still_exact(kind):
+    """ann_by_vector has no limit on ef (template.rs:306-311).  Above 1024 the list and the visited set live in
+    HBM scratch (hx_search_spill_kernel): ids, distances and counters are still the oracle's, including ef
+    larger than the index, n in the thousands, the search_layer seam, and a visited table that starts too
+    small and is doubled by the host"""
+    n, d, m = 5000, 100, 16
+    vs, qs = rand_vectors(n, d, 21), rand_vectors(24, d, 22)
+    index, orc = both(vs, O.draw_levels(n, m, 23), m, kind=kind, threads=4)
+    for ef, k in ((1025, 10), (1500, 1200), (4096, 4096), (6000, 50)):
+        assert_search_equal(index.search_batch(qs, k, ef), orc.search_batch(qs, k, ef), "ef=%d n=%d" % (ef, k))
+    ids = index.ann_by_vector(qs[0], 10, 2048)  # the one-query entry of the reference's API
+    assert ids == [int(x) for x in orc.search_batch(qs[:1], 10, 2048)[0][0]]
+    # device-resident entry + finish
+    import torch
+    dev = torch.device("cuda:0")
+    dQ = torch.from_numpy(qs).to(dev)
+    nq, k, ef = qs.shape[0], 20, 1300
+    d_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    d_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    d_c = torch.empty(nq, dtype=torch.int32, device=dev)
+    d_s = torch.empty((nq, 4), dtype=torch.int32, device=dev)
+    index.search_batch_device(dQ.data_ptr(), nq, k, ef, d_ids.data_ptr(), d_d.data_ptr(), d_c.data_ptr(), d_s.data_ptr(), 0)
+    index.search_batch_device_finish(dQ.data_ptr(), nq, k, ef, d_ids.data_ptr(), d_d.data_ptr(), d_c.data_ptr(), d_s.data_ptr(), 0)
+    w_ids, w_d, _, _ = orc.search_batch(qs, k, ef)
+    assert np.array_equal(d_ids.cpu().numpy().view(np.uint32), w_ids) and np.array_equal(d_d.cpu().numpy(), w_d)
 
 
 @pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])

@@ -82,8 +82,9 @@ def test_replica_made_by_device_copies_answers_like_its_source(kind):
     for i in range(32):
         bad.header[i] = desc.header[i]
     bad.bytes[1] -= 4
+    fresh = H.HNSW.new(m, 32, d, kind)  # (kept in a name: a temporary would be freed under the call)
     with pytest.raises(H.HnswError):
-        _lib.check(L.hnsw_snapshot_adopt(H.HNSW.new(m, 32, d, kind)._h, C.byref(bad)))
+        _lib.check(L.hnsw_snapshot_adopt(fresh._h, C.byref(bad)))
 
 
 def _replicate_worker(rank, world, port, outdir, backend):
