@@ -51,6 +51,9 @@ struct hnsw_index {
     // but not all of them are connected, so every later search or build on this handle fails loudly
     // instead of answering from an incomplete graph
     bool incomplete_build = false;
+    // option "metric_cosine" (an extension, the reference is Euclidean only): rows are normalised to unit
+    // length as they are inserted and queries as they arrive, so the L2 order behind is the cosine order
+    bool cosine = false;
     std::mutex mu;
     std::mutex pool_mu;
     std::vector<std::unique_ptr<SearchScratch>> pool;
@@ -90,6 +93,52 @@ int reject_replica(const hnsw_index *h, const char *what) {
     set_error("%s: this handle is a device-only replica (hnsw_snapshot_adopt); it holds no host copy of the index", what);
     return HNSW_ERR_ARG;
 }
+
+// The cosine option on the way in: a unit-length copy of n rows, by the same operations in the same order as
+// hx_normalise_rows_kernel (metric.hip) -- one left-to-right f32 sum of squares, correctly rounded sqrt and
+// division, no FMA (this file is compiled with -ffp-contract=off).  Returns rows itself when the option is off.
+const float *cosine_rows(const hnsw_index *h, const float *rows, uint64_t n, std::vector<float> &keep) {
+    if (!h->cosine || !rows) return rows;
+    const uint32_t d = h->host->dim;
+    keep.resize((size_t)n * d);
+    for (uint64_t i = 0; i < n; i++) {
+        const float *x = rows + i * d;
+        float s = 0.0f;
+        for (uint32_t e = 0; e < d; e++) {
+            const float t = x[e] * x[e];
+            s += t;
+        }
+        const float nrm = sqrtf(s);
+        float *y = &keep[(size_t)i * d];
+        for (uint32_t e = 0; e < d; e++) y[e] = x[e] / nrm;
+    }
+    return keep.data();
+}
+// ... and for queries already copied to the device
+int cosine_queries(const hnsw_index *h, void *d_Q, uint64_t nq, hipStream_t stream) {
+    if (!h->cosine) return HNSW_OK;
+    return hx::launch_normalise_rows(static_cast<float *>(d_Q), nq, h->dev.view.dim, stream);
+}
+
+// ... and for queries the caller keeps in HBM (const to us): a stream-ordered unit-length copy
+struct DeviceQueries {
+    const float *q = nullptr;
+    void *tmp = nullptr;
+    hipStream_t st = nullptr;
+    int prepare(const hnsw_index *h, const float *d_Q, uint64_t nq, hipStream_t stream) {
+        q = d_Q;
+        st = stream;
+        if (!h->cosine) return HNSW_OK;
+        const size_t bytes = (size_t)nq * h->dev.view.dim * 4;
+        HIP_TRY(hipMallocAsync(&tmp, bytes, stream));
+        HIP_TRY(hipMemcpyAsync(tmp, d_Q, bytes, hipMemcpyDeviceToDevice, stream));
+        q = static_cast<const float *>(tmp);
+        return hx::launch_normalise_rows(static_cast<float *>(tmp), nq, h->dev.view.dim, stream);
+    }
+    ~DeviceQueries() {
+        if (tmp) (void)hipFreeAsync(tmp, st);
+    }
+};
 
 int ensure_uploaded(hnsw_index *h) {
     std::lock_guard<std::mutex> g(h->mu);
@@ -214,6 +263,7 @@ int search_host(hnsw_index *h, hx::SearchArgs a_host, const float *Q, uint64_t n
     SearchScratch &s = *lease.s;
     unsigned char *dv = static_cast<unsigned char *>(s.dev), *hv = static_cast<unsigned char *>(s.pin);
     HIP_TRY(hipMemcpyAsync(dv + o_q, Q, nq * d * 4, hipMemcpyHostToDevice, s.stream));
+    if ((rc = cosine_queries(h, dv + o_q, nq, s.stream))) return rc;
     hx::SearchArgs a = a_host;
     a.Q = reinterpret_cast<const float *>(dv + o_q);
     a.out_ids = reinterpret_cast<uint32_t *>(dv + o_out + r_ids);
@@ -965,6 +1015,8 @@ int hnsw_insert_bulk_levels(hnsw_index *h, const float *rows, uint64_t n, uint32
     if (!h || !rows) return HNSW_ERR_ARG;
     if (is_replica(h)) return reject_replica(h, "hnsw_insert_bulk");
     if (h->incomplete_build) return check_search_args(h, 1);
+    std::vector<float> unit;
+    rows = cosine_rows(h, rows, n, unit);
     if (h->gpu_build == 2) return device_build_guard(h, [&] { return gpu_insert_bulk_full(h, rows, n, nb_threads, verbose, levels); });
     if (h->gpu_build) return device_build_guard(h, [&] { return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels); });
     return h->host->insert_bulk(rows, n, nb_threads, verbose != 0, levels);
@@ -978,6 +1030,8 @@ int hnsw_insert_bulk_sharded(hnsw_index *h, const float *rows, uint64_t n, uint3
                              uint64_t slot_bytes, hnsw_allgather_fn allgather, void *ctx) {
     if (!h || !rows || world == 0 || rank >= world) return HNSW_ERR_ARG;
     if (is_replica(h)) return reject_replica(h, "hnsw_insert_bulk_sharded");
+    std::vector<float> unit;
+    rows = cosine_rows(h, rows, n, unit);
     ShardCtx sh{rank, world, static_cast<unsigned char *>(d_send), static_cast<unsigned char *>(d_recv), slot_bytes,
                 allgather, ctx};
     if (h->incomplete_build) return check_search_args(h, 1);
@@ -988,6 +1042,8 @@ int hnsw_insert_bulk_device(hnsw_index *h, const float *rows, uint64_t n, uint32
     if (!h || !rows) return HNSW_ERR_ARG;
     if (is_replica(h)) return reject_replica(h, "hnsw_insert_bulk_device");
     if (h->incomplete_build) return check_search_args(h, 1);
+    std::vector<float> unit;
+    rows = cosine_rows(h, rows, n, unit);
     if (h->gpu_build == 1) return device_build_guard(h, [&] { return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels); });
     return device_build_guard(h, [&] { return gpu_insert_bulk_full(h, rows, n, nb_threads, verbose, levels); });
 }
@@ -998,11 +1054,15 @@ int hnsw_insert_vec_level(hnsw_index *h, const float *v, int level, uint32_t *ou
     if (!h || !v || level > 255) return HNSW_ERR_ARG;
     if (is_replica(h)) return reject_replica(h, "hnsw_insert_vec");
     if (h->incomplete_build) return check_search_args(h, 1);
+    std::vector<float> unit;
+    v = cosine_rows(h, v, 1, unit);
     return h->host->insert_vec(v, level, out_id);
 }
 int hnsw_import_points(hnsw_index *h, const float *rows, uint64_t n, const uint8_t *levels) {
     if (!h || !rows) return HNSW_ERR_ARG;
     if (is_replica(h)) return reject_replica(h, "hnsw_import_points");
+    std::vector<float> unit;
+    rows = cosine_rows(h, rows, n, unit);
     return h->host->import_points(rows, n, levels);
 }
 int hnsw_import_layer(hnsw_index *h, uint32_t layer, uint64_t n_nodes, const uint32_t *node_ids,
@@ -1043,7 +1103,9 @@ int hnsw_search_batch_device(hnsw_index *h, const float *d_Q, uint64_t nq, uint3
     if (!d_Q || !d_ids || !d_stats || nq > 0x7FFFFFFFull) return HNSW_ERR_ARG;
     rc = ensure_uploaded(h);
     if (rc != HNSW_OK) return rc;
-    hx::SearchArgs a = ann_args(h->dev.view, d_Q, n, ef, d_ids, d_dists, d_counts, d_stats);
+    DeviceQueries dq;
+    if ((rc = dq.prepare(h, d_Q, nq, static_cast<hipStream_t>(stream)))) return rc;
+    hx::SearchArgs a = ann_args(h->dev.view, dq.q, n, ef, d_ids, d_dists, d_counts, d_stats);
 #ifdef HX_STAMPS
     a.dbg = reinterpret_cast<unsigned long long *>(getenv("HX_DBG_PTR") ? strtoull(getenv("HX_DBG_PTR"), nullptr, 0) : 0);
 #endif
@@ -1069,7 +1131,9 @@ int hnsw_search_batch_device_finish(hnsw_index *h, const float *d_Q, uint64_t nq
     if ((rc = lease.prepare(h->dev.device, align256(nq * 4), st_bytes))) return rc;
     SearchScratch &s = *lease.s;
     hnsw_query_stats *st = static_cast<hnsw_query_stats *>(s.pin);
-    hx::SearchArgs a = ann_args(v, d_Q, n, ef, d_ids, d_dists, d_counts, d_stats);
+    DeviceQueries dq;  // a re-run reads the queries again: the unit-length copy under the cosine option
+    if ((rc = dq.prepare(h, d_Q, nq, stream))) return rc;
+    hx::SearchArgs a = ann_args(v, dq.q, n, ef, d_ids, d_dists, d_counts, d_stats);
     uint32_t slots = hx::default_slots_log2(ef, v.S0);
     std::vector<uint32_t> sel;
     while (true) {
@@ -1111,6 +1175,7 @@ int hnsw_distance_batch(hnsw_index *h, const float *q, const uint32_t *ids, uint
         (rc = dst.alloc(4)))
         return rc;
     HIP_TRY(hipMemcpy(dq.p, q, v.dim * 4, hipMemcpyHostToDevice));
+    if ((rc = cosine_queries(h, dq.p, 1, nullptr))) return rc;
     HIP_TRY(hipMemcpy(dids.p, ids, k * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(dst.p, 0, 4));
     rc = hx::launch_distance_batch(v, dq.as<float>(), dids.as<uint32_t>(), k, dout.as<float>(),
@@ -1198,6 +1263,7 @@ int hnsw_brute_force(hnsw_index *h, const float *Q, uint64_t nq, uint32_t k, uin
     for (uint64_t q0 = 0; q0 < nq; q0 += batch) {
         const uint64_t nb = std::min(batch, nq - q0);
         HIP_TRY(hipMemcpy(dQ.p, Q + q0 * v.dim, nb * v.dim * 4, hipMemcpyHostToDevice));
+        if ((rc = cosine_queries(h, dQ.p, nb, nullptr))) return rc;
         HIP_TRY(hipMemset(dSt.p, 0, 4));
         rc = hx::launch_brute_force(v, dQ.as<float>(), nb, k, nseg, dIds.as<uint32_t>(),
                                     dDists.as<float>(), dSt.as<int32_t>(), nullptr);
@@ -1273,6 +1339,7 @@ int hnsw_brute_force_fast(hnsw_index *h, const float *Q, uint64_t nq, uint32_t k
         const uint64_t nb = std::min(batch, nq - q0);
         const uint32_t ntile = (uint32_t)((nb + 31) / 32);
         HIP_TRY(hipMemcpy(dQ.p, Q + q0 * v.dim, nb * v.dim * 4, hipMemcpyHostToDevice));
+        if ((rc = cosine_queries(h, dQ.p, nb, nullptr))) return rc;
         rc = hx::launch_brute_mfma(v, dXn.as<float>(), dQ.as<float>(), (uint32_t)nb, nseg, dS.as<float>(),
                                    dI.as<uint32_t>(), nullptr);
         if (rc != HNSW_OK) return rc;
@@ -1476,6 +1543,11 @@ int hnsw_set_option(hnsw_index *h, const char *key, int64_t value) {
         h->dev.fat_budget_bytes = (uint64_t)value << 20;
     } else if (!strcmp(key, "gpu_build")) {
         h->gpu_build = (int)value;
+        return HNSW_OK;
+    } else if (!strcmp(key, "metric_cosine")) {
+        // points already stored stay as they are: set it before the first insert (or on a loaded index whose
+        // rows were stored under it -- the reference's file format has no field for a metric)
+        h->cosine = value != 0;
         return HNSW_OK;
     } else if (!strcmp(key, "gpu_build_batch_max")) {
         if (value < 1) {

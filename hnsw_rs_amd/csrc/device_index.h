@@ -188,6 +188,9 @@ int launch_brute_mfma(const DevView &v, const float *d_xn, const float *d_Q, uin
 int launch_pair_distance(const DevView &v, const float *d_Q, const uint32_t *d_qidx, const uint32_t *d_pidx, uint64_t n,
                          float *d_out, hipStream_t stream);
 
+// the cosine option: rows (queries) normalised in place to unit length (metric.hip)
+int launch_normalise_rows(float *d_rows, uint64_t n, uint32_t d, hipStream_t stream);
+
 // out[i] = dist(point ids[i], query) for one query; d_q is the raw query (dim floats, device)
 int launch_distance_batch(const DevView &v, const float *d_q, const uint32_t *d_ids, uint64_t k,
                           float *d_out, int32_t *d_status, hipStream_t stream);

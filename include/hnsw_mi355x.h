@@ -241,6 +241,15 @@ int hnsw_device_bytes(const hnsw_index *h, uint64_t *bytes);
  *   "gpu_build"        0 (default): hnsw_insert_bulk(_levels) is the CPU build; 2: it runs the on-device
  *                      build; 1: on-device searches with connect / prune on host threads (also what
  *                      hnsw_insert_bulk_device does while this is 1)
+ *   "metric_cosine"    0 (default) / 1.  AN EXTENSION: the reference has Euclidean distance only
+ *                      (vectors/src/lib.rs:10-27), so there is nothing to be bit-identical to -- parity unpinned.
+ *                      With 1, every row is normalised to unit length as it is inserted and every query as it
+ *                      arrives (one left-to-right f32 sum of squares, correctly rounded sqrt and division, the
+ *                      same on host and device); behind that everything is the reference's L2 arithmetic, whose
+ *                      order on unit vectors is the cosine order.  Distances returned are Euclidean distances
+ *                      of the unit vectors (d^2 = 2 - 2 cos); hnsw_get_vector returns the stored unit rows; a
+ *                      zero vector is HNSW_ERR_NAN_INPUT.  Set it before the first insert; save / load do not
+ *                      carry it (the reference's file format has no such field): set it again after a load.
  *   "gpu_build_batch_max", "gpu_build_batch_div"
  *                      the on-device build inserts min(max, connected / div) points at a time (defaults
  *                      8192 and 8); 256 and 64 stand closer to the reference's one-at-a-time insertion

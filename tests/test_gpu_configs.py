@@ -273,3 +273,42 @@ def test_full_size_properties_1m_x_100d(kind):
     got, _, _, _ = idx.search_batch(qs[:128], n, 68)
     hit = sum(int(truth[i, 0] in got[i]) for i in range(128))
     assert hit >= 126, hit
+
+
+@pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
+def test_cosine_option_is_l2_on_unit_vectors(kind):
+    """"metric_cosine" = 1 on raw rows and raw queries answers exactly like a plain index over rows and queries
+    normalised beforehand by the same arithmetic (the option is an extension: the reference has no cosine,
+    vectors/src/lib.rs:10-27); the neighbours are the ones of largest cosine similarity"""
+    from tests.test_host_build import _unit_rows
+    n, d, m = 6000, 100, 16
+    vs = H.synth_rows(0, 0x5EED0001, 0, n, d) * np.float32(2.5)
+    qs = H.synth_rows(0, 0x5EED0002, 0, 128, d) * np.float32(0.3)
+    lv = H.draw_levels(m, n)
+    cos = H.HNSW.new(m, 32, d, kind)
+    cos.set_option("metric_cosine", 1)
+    cos.insert_bulk(vs, 4, False, levels=lv)
+    ref = H.HNSW.new(m, 32, d, kind).insert_bulk(_unit_rows(vs), 4, False, levels=lv)
+    uq = _unit_rows(qs)
+    for ef in (16, 64):
+        assert_search_equal(cos.search_batch(qs, 10, ef), ref.search_batch(uq, 10, ef), "cosine ef=%d" % ef)
+    assert np.array_equal(cos.brute_force(qs[:8], 10)[0], ref.brute_force(uq[:8], 10)[0])
+    if kind == H.VEC_F32:
+        # device-resident queries go through the same normalisation
+        import torch
+        dev = torch.device("cuda:0")
+        dQ = torch.from_numpy(qs).to(dev)
+        ids = torch.empty((128, 10), dtype=torch.int32, device=dev)
+        dd = torch.empty((128, 10), dtype=torch.float32, device=dev)
+        cnt = torch.empty(128, dtype=torch.int32, device=dev)
+        st = torch.empty((128, 4), dtype=torch.int32, device=dev)
+        cos.search_batch_device(dQ.data_ptr(), 128, 10, 64, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), st.data_ptr(), 0)
+        cos.search_batch_device_finish(dQ.data_ptr(), 128, 10, 64, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), st.data_ptr(), 0)
+        w = ref.search_batch(uq, 10, 64)
+        assert np.array_equal(ids.cpu().numpy().view(np.uint32), w[0]) and np.array_equal(dd.cpu().numpy(), w[1])
+        assert torch.equal(dQ.cpu(), torch.from_numpy(qs))  # the caller's queries are left as they were
+        # the exact top-10 by cosine similarity (float64) is what the exhaustive scan returns
+        sims = (_unit_rows(vs).astype(np.float64) @ uq[:8].astype(np.float64).T).T
+        best = np.argsort(-sims, axis=1)[:, :10]
+        bf = cos.brute_force(qs[:8], 10)[0]
+        assert np.mean([len(set(a.tolist()) & set(b.tolist())) for a, b in zip(bf, best)]) >= 9.9

@@ -204,3 +204,29 @@ def test_snapshot_replication_argument_checks_without_a_device():
     desc.header[1] = 1
     assert L.hnsw_snapshot_adopt(full._h, C.byref(desc)) == _lib.ERR_ARG        # receiver must be empty
     assert b"must be empty" in L.hnsw_last_error()
+
+
+def _unit_rows(a):
+    """the library's normalisation restated in numpy: one left-to-right f32 sum of squares (cumsum accumulates
+    sequentially), f32 sqrt, f32 division"""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    ss = np.cumsum(a * a, axis=1, dtype=np.float32)[:, -1]
+    return a / np.sqrt(ss, dtype=np.float32)[:, None]
+
+
+def test_cosine_option_normalises_rows_on_the_way_in():
+    """"metric_cosine" (an extension: the reference is Euclidean only, vectors/src/lib.rs:10-27): stored rows are
+    the unit vectors, bit for bit what the numpy restatement gives; a zero vector is refused"""
+    vs = rand_vectors(300, 24, 5) * np.float32(3.0) - np.float32(1.0)
+    idx = H.HNSW.new(8, None, 24, H.VEC_F32)
+    idx.set_option("metric_cosine", 1)
+    idx.insert_bulk(vs, 2, False)
+    want = _unit_rows(vs)
+    got = np.stack([idx.get_point(i).get_vals() for i in range(300)])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    node = idx.insert_vec(vs[7] * np.float32(10.0))
+    assert np.array_equal(idx.get_point(node).get_vals().view(np.uint32), _unit_rows(vs[7:8] * np.float32(10.0))[0].view(np.uint32))
+    with pytest.raises(H.HnswError):
+        idx.insert_vec(np.zeros(24, dtype=np.float32))  # 0 / 0: no direction
+    plain = H.HNSW.new(8, None, 24, H.VEC_F32).insert_bulk(vs, 2, False)
+    assert np.array_equal(plain.get_point(3).get_vals(), vs[3])  # off by default
