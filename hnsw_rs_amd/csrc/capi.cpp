@@ -341,8 +341,8 @@ int gpu_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_th
     using hx::NodeID;
     hx::HostIndex &host = *h->host;
     if (nb_threads == 0) nb_threads = 1;
-    if (host.params.m > 32 || host.params.ef_cons > 512) {
-        set_error("on-device build supports m <= 32 and ef_construction <= 512");
+    if (host.params.m > 128 || host.params.ef_cons > 512) {
+        set_error("on-device build supports m <= 128 and ef_construction <= 512");
         return HNSW_ERR_ARG;
     }
     const uint64_t n_before = host.len();
@@ -623,8 +623,8 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     using hx::NodeID;
     hx::HostIndex &host = *h->host;
     if (nb_threads == 0) nb_threads = 1;
-    if (host.params.m > 32 || host.params.ef_cons > 512) {
-        set_error("on-device build supports m <= 32 and ef_construction <= 512");
+    if (host.params.m > 128 || host.params.ef_cons > 512) {
+        set_error("on-device build supports m <= 128 and ef_construction <= 512");
         return HNSW_ERR_ARG;
     }
     if (host.len() + n >= (1ull << hx::HX_EDGE_ID_BITS)) {  // edge records carry 30-bit ids

@@ -1911,10 +1911,10 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
     const uint32_t hslots = 1u << slots_log2, hmask = hslots - 1;
     const uint32_t vis_limit = hslots - (hslots >> 2);
     u64 *perm = reinterpret_cast<u64 *>(smem + 4ull * hslots);
-    u64 *selk = perm + 64 * R;                                   // [64] selected keys
+    u64 *selk = perm + 64 * R;                                   // [128] selected keys (m <= 128)
     const uint32_t yq_bytes =
         ((KIND == HNSW_VEC_QUANT8 ? 2u * (v.half_bytes - 8) * 4u : v.dim * 4u) + 15u) & ~15u;
-    float *yq = reinterpret_cast<float *>(selk + 64);
+    float *yq = reinterpret_cast<float *>(selk + 128);
     float *yqe = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(yq) + yq_bytes);
     // cooperative row gather (f32 rows of whole lines): the stage image lives in perm (4 KiB, used by the
     // merges only, never during a distance pass), the rank -> id words behind the staged rows
@@ -2135,17 +2135,20 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
             }
         }
         wave_fence();
-        // save_layer_results + the selection seeds the next layer
-        const u64 mine = (uint32_t)lane < ns ? selk[lane] : KEY_INVALID;
-        if ((uint32_t)lane < ns) {
-            o_ids[(size_t)layer * m + lane] = (uint32_t)mine;
-            o_d[(size_t)layer * m + lane] = __builtin_bit_cast(float, (uint32_t)(mine >> 32));
-        }
+        // save_layer_results + the selection seeds the next layer (up to 128 selected: two rounds of 64)
 #pragma unroll
         for (int r = 0; r < R; r++) wl.L[r] = KEY_INVALID;
         wl.n_cur = 0;
         wl.last_key = KEY_INVALID;
-        wl.merge(mine, max(ns, 1u), perm, lane);
+        for (uint32_t j0 = 0; j0 < max(ns, 1u); j0 += 64) {
+            const uint32_t j = j0 + (uint32_t)lane;
+            const u64 mine = j < ns ? selk[j] : KEY_INVALID;
+            if (j < ns) {
+                o_ids[(size_t)layer * m + j] = (uint32_t)mine;
+                o_d[(size_t)layer * m + j] = __builtin_bit_cast(float, (uint32_t)(mine >> 32));
+            }
+            wl.merge(mine, max(ns, 1u), perm, lane);
+        }
     }
     if (__ballot(status != HNSW_OK)) {
         int32_t st = status;
@@ -2159,8 +2162,11 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         uint32_t total = 0;
         for (uint32_t l = 0; l <= level; l++) {
-            const uint32_t id = (uint32_t)lane < m ? o_ids[(size_t)l * m + lane] : HX_EMPTY_SLOT;
-            total += (uint32_t)__popcll(__ballot(id != HX_EMPTY_SLOT));
+            for (uint32_t j0 = 0; j0 < m; j0 += 64) {
+                const uint32_t j = j0 + (uint32_t)lane;
+                const uint32_t id = j < m ? o_ids[(size_t)l * m + j] : HX_EMPTY_SLOT;
+                total += (uint32_t)__popcll(__ballot(id != HX_EMPTY_SLOT));
+            }
         }
         // emit_own (sharded build): the point's own rows travel as records too -- (layer, p <- n) next
         // to (layer, n <- p) -- so that the record list alone carries the whole batch to every replica
@@ -2188,21 +2194,28 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
         } else {
             for (uint32_t l = 0; l <= level; l++) {
                 const uint32_t S = l == 0 ? v.S0 : v.S1;
-                const uint32_t id = (uint32_t)lane < m ? o_ids[(size_t)l * m + lane] : HX_EMPTY_SLOT;
-                if (!a.emit_own) {
-                    uint32_t *row = l == 0 ? a.adj0_mut + (size_t)p * S
-                                           : a.adj_up_mut + ((size_t)v.upper_base[p] + l - 1) * S;
-                    if ((uint32_t)lane < S) row[lane] = id;
+                // the layer's selection is a prefix of its m output slots: cnt of them are filled
+                uint32_t cnt = 0;
+                for (uint32_t j0 = 0; j0 < m; j0 += 64) {
+                    const uint32_t j = j0 + (uint32_t)lane;
+                    cnt += (uint32_t)__popcll(__ballot(j < m && o_ids[(size_t)l * m + j] != HX_EMPTY_SLOT));
                 }
-                const u64 vm = __ballot(id != HX_EMPTY_SLOT);  // a prefix of the lanes
-                const uint32_t cnt = (uint32_t)__popcll(vm);
-                if (id != HX_EMPTY_SLOT) {
-                    const uint32_t db = __builtin_bit_cast(uint32_t, o_d[(size_t)l * m + lane]);
-                    a.req_keys[base + lane] = hx_edge_key(l, id, p);
-                    a.req_vals[base + lane] = db;
-                    if (a.emit_own) {
-                        a.req_keys[base + cnt + lane] = hx_edge_key(l, p, id);
-                        a.req_vals[base + cnt + lane] = db;
+                for (uint32_t j0 = 0; j0 < max(S, m); j0 += 64) {
+                    const uint32_t j = j0 + (uint32_t)lane;
+                    const uint32_t id = j < m ? o_ids[(size_t)l * m + j] : HX_EMPTY_SLOT;
+                    if (!a.emit_own) {
+                        uint32_t *row = l == 0 ? a.adj0_mut + (size_t)p * S
+                                               : a.adj_up_mut + ((size_t)v.upper_base[p] + l - 1) * S;
+                        if (j < S) row[j] = id;
+                    }
+                    if (id != HX_EMPTY_SLOT) {
+                        const uint32_t db = __builtin_bit_cast(uint32_t, o_d[(size_t)l * m + j]);
+                        a.req_keys[base + j] = hx_edge_key(l, id, p);
+                        a.req_vals[base + j] = db;
+                        if (a.emit_own) {
+                            a.req_keys[base + cnt + j] = hx_edge_key(l, p, id);
+                            a.req_vals[base + cnt + j] = db;
+                        }
                     }
                 }
                 base += cnt * per_edge;
@@ -2224,14 +2237,18 @@ hx_scatter_rows_kernel(uint32_t *dst, uint32_t S, const uint32_t *row_index, con
 
 int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipStream_t stream) {
     if (nblocks == 0) return HNSW_OK;
-    if (a.m > 32 || a.m == 0 || a.ef_cons > 64 * HX_MAX_R) {
-        set_error("on-device build supports m <= 32 and ef_construction <= 512");
+    if (a.m > 128 || a.m == 0 || a.ef_cons > 64 * HX_MAX_R) {
+        set_error("on-device build supports m <= 128 and ef_construction <= 512");
         return HNSW_ERR_ARG;
     }
-    const uint32_t slots_log2 = 12 + (a.ef_cons > 64 ? 1 : 0) + (a.ef_cons > 160 ? 1 : 0);
+    // visited table: what ef_cons list entries with rows of S0 slots visit (m <= 32: 4096 / 8192 / 16384 slots as
+    // before; the 128- and 256-slot rows of m = 64 / 128 take up to 32768 slots = 128 KiB, one wave per CU -- a
+    // point that still fills it takes the CPU path after the build, like every point whose search fails)
+    uint32_t slots_log2 = 12 + (a.ef_cons > 64 ? 1 : 0) + (a.ef_cons > 160 ? 1 : 0);
+    if (v.S0 > 64) slots_log2 = std::max(slots_log2, std::min(15u, default_slots_log2(a.ef_cons, v.S0)));
     const size_t yq_bytes =
         ((v.kind == HNSW_VEC_QUANT8 ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4) + 15) & ~15ull;
-    const size_t lds = (4ull << slots_log2) + 64ull * HX_MAX_R * 8 + 64 * 8 + 2 * yq_bytes + 256 /* rank -> id words */;
+    const size_t lds = (4ull << slots_log2) + 64ull * HX_MAX_R * 8 + 128 * 8 + 2 * yq_bytes + 256 /* rank -> id words */;
     if (lds > 160 * 1024) {
         set_error("insert kernel needs %zu bytes of LDS", lds);
         return HNSW_ERR_ARG;
@@ -2296,13 +2313,16 @@ __device__ __forceinline__ uint32_t edge_group_size(const uint64_t *keys, uint32
     }
 }
 
-template <int KIND, int DS>
+// RS = registers per lane that hold one adjacency row (slot 64 r + lane): 1 for rows of up to 64 slots
+// (m <= 32), 2 / 4 for the 128- / 256-slot layer-0 rows of m = 64 / 128 (the reference's own build benches
+// use M in {32, 64, 128}, hnsw/benches/hnsw_benchmarks.rs:7)
+template <int KIND, int DS, int RS>
 __global__ void __launch_bounds__(64)
 hx_connect_kernel(const DevView v, const ConnectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64 *perm = reinterpret_cast<u64 *>(smem);       // [64]
-    u64 *ekeys = perm + 64;                           // [64] keys of the existing neighbours
-    float *yq = reinterpret_cast<float *>(ekeys + 64);
+    u64 *perm = reinterpret_cast<u64 *>(smem);       // [64 RS]
+    u64 *ekeys = perm + 64 * RS;                      // [64 RS] keys of the existing neighbours
+    float *yq = reinterpret_cast<float *>(ekeys + 64 * RS);
     const int lane = threadIdx.x;
     const uint32_t lo = blockIdx.x;
     if (lo >= a.count) return;
@@ -2313,7 +2333,7 @@ hx_connect_kernel(const DevView v, const ConnectArgs a) {
     const uint32_t layer = (uint32_t)(head >> (2 * HX_EDGE_ID_BITS));
     const uint32_t S = layer == 0 ? v.S0 : v.S1;
     const uint32_t cap = layer == 0 ? 2 * a.m : a.m;
-    if (n >= v.n_points || layer >= v.nb_layers || (layer > 0 && v.upper_base[n] == HX_EMPTY_SLOT)) {
+    if (n >= v.n_points || layer >= v.nb_layers || (layer > 0 && v.upper_base[n] == HX_EMPTY_SLOT) || S > 64u * RS) {
         *a.status = HNSW_ERR_NODE_NOT_IN_GRAPH;  // a malformed record: never touch memory for it
         return;
     }
@@ -2325,28 +2345,46 @@ hx_connect_kernel(const DevView v, const ConnectArgs a) {
     const int cslot = lane / LPC;
     const bool first = (LPC == 1) || (h == 0);
 
-    const uint32_t cur = (uint32_t)lane < S ? row[lane] : HX_EMPTY_SLOT;
-    const bool has = cur != HX_EMPTY_SLOT;
-    const u64 hm = __ballot(has);
-    const uint32_t deg = (uint32_t)__popcll(hm);
+    uint32_t cur[RS];
+    u64 hm[RS];
+    uint32_t deg = 0;
+#pragma unroll
+    for (int r = 0; r < RS; r++) {
+        const uint32_t slot = 64u * r + (uint32_t)lane;
+        cur[r] = slot < S ? row[slot] : HX_EMPTY_SLOT;
+        hm[r] = __ballot(cur[r] != HX_EMPTY_SLOT);
+        deg += (uint32_t)__popcll(hm[r]);
+    }
     if (deg + k <= cap && deg + k <= S) {  // room for every source: append
-        const uint32_t pos = (uint32_t)__popcll(hm & ((1ull << lane) - 1));
-        if (has) row[pos] = cur;  // all reads of the row happened above
+        uint32_t before = 0;               // (all reads of the row happened above)
+#pragma unroll
+        for (int r = 0; r < RS; r++) {
+            if (cur[r] != HX_EMPTY_SLOT) row[before + (uint32_t)__popcll(hm[r] & ((1ull << lane) - 1))] = cur[r];
+            before += (uint32_t)__popcll(hm[r]);
+        }
         for (uint32_t j = lane; j < k; j += 64) row[deg + j] = (uint32_t)(a.keys[lo + j] & HX_EDGE_ID_MASK);
         for (uint32_t j = deg + k + lane; j < S; j += 64) row[j] = HX_EMPTY_SLOT;
         return;
     }
     // ---- prune: keep the `cap` nearest of existing ∪ sources ----
     stage_row<KIND>(v, n, yq, lane);
-    WaveList<1> wl;
-    wl.L[0] = KEY_INVALID;
+    WaveList<RS> wl;
+#pragma unroll
+    for (int r = 0; r < RS; r++) {
+        wl.L[r] = KEY_INVALID;
+        ekeys[64 * r + lane] = KEY_INVALID;
+    }
     wl.n_cur = 0;
     wl.last_key = KEY_INVALID;
-    ekeys[lane] = KEY_INVALID;
     wave_fence();
     for (uint32_t c0 = 0; c0 < S; c0 += CHUNK) {  // existing neighbours, CHUNK at a time
         const uint32_t slot = c0 + cslot;
-        const uint32_t id = (uint32_t)__shfl((int)cur, (int)(slot & 63));
+        uint32_t id = HX_EMPTY_SLOT;
+#pragma unroll
+        for (int r = 0; r < RS; r++) {
+            const uint32_t t = (uint32_t)__shfl((int)cur[r], (int)(slot & 63));
+            if ((slot >> 6) == (uint32_t)r) id = t;
+        }
         const bool act = slot < S && id < v.n_points;
         if (slot < S && id != HX_EMPTY_SLOT && id >= v.n_points) *a.status = HNSW_ERR_NODE_NOT_IN_GRAPH;
         const float dist = dist_build<KIND, DS>(v, id, act, h, yq);
@@ -2362,7 +2400,11 @@ hx_connect_kernel(const DevView v, const ConnectArgs a) {
     };
     for (uint32_t j0 = 0; j0 < k; j0 += 64) wl.merge(source_key(j0 + lane), cap, perm, lane);
     wave_fence();
-    if ((uint32_t)lane < S) row[lane] = (uint32_t)lane < wl.n_cur ? (uint32_t)wl.L[0] : HX_EMPTY_SLOT;
+#pragma unroll
+    for (int r = 0; r < RS; r++) {
+        const uint32_t slot = 64u * r + (uint32_t)lane;
+        if (slot < S) row[slot] = slot < wl.n_cur ? (uint32_t)wl.L[r] : HX_EMPTY_SLOT;
+    }
     // report what fell out: key > the last kept key (keys are distinct)
     const u64 lastk = wl.n_cur >= cap ? wl.last_key : KEY_INVALID;
     auto emit = [&](u64 key) {
@@ -2380,7 +2422,8 @@ hx_connect_kernel(const DevView v, const ConnectArgs a) {
                 *a.status = HNSW_ERR_OVERFLOW;
         }
     };
-    emit(ekeys[lane]);
+#pragma unroll
+    for (int r = 0; r < RS; r++) emit(ekeys[64 * r + lane]);
     for (uint32_t j0 = 0; j0 < k; j0 += 64) emit(source_key(j0 + lane));
 }
 
@@ -2389,6 +2432,7 @@ hx_connect_kernel(const DevView v, const ConnectArgs a) {
 // to x's LAST neighbour is kept (isolate_node, graph.rs:85-94): such a refusal is reported and the
 // host restores the reverse direction after the build.
 // ---------------------------------------------------------------------------------------------
+template <int RS>
 __global__ void __launch_bounds__(64)
 hx_remove_kernel(const DevView v, const ConnectArgs a) {
     const int lane = threadIdx.x;
@@ -2400,17 +2444,25 @@ hx_remove_kernel(const DevView v, const ConnectArgs a) {
     const uint32_t x = (uint32_t)((head >> HX_EDGE_ID_BITS) & HX_EDGE_ID_MASK);
     const uint32_t layer = (uint32_t)(head >> (2 * HX_EDGE_ID_BITS));
     const uint32_t S = layer == 0 ? v.S0 : v.S1;
-    if (x >= v.n_points || layer >= v.nb_layers || (layer > 0 && v.upper_base[x] == HX_EMPTY_SLOT)) {
+    if (x >= v.n_points || layer >= v.nb_layers || (layer > 0 && v.upper_base[x] == HX_EMPTY_SLOT) || S > 64u * RS) {
         *a.status = HNSW_ERR_NODE_NOT_IN_GRAPH;
         return;
     }
     uint32_t *row = layer == 0 ? a.adj0_mut + (size_t)x * S
                                : a.adj_up_mut + ((size_t)v.upper_base[x] + layer - 1) * S;
-    uint32_t cur = (uint32_t)lane < S ? row[lane] : HX_EMPTY_SLOT;
-    uint32_t deg = (uint32_t)__popcll(__ballot(cur != HX_EMPTY_SLOT));
+    uint32_t cur[RS];
+    uint32_t deg = 0;
+#pragma unroll
+    for (int r = 0; r < RS; r++) {
+        const uint32_t slot = 64u * r + (uint32_t)lane;
+        cur[r] = slot < S ? row[slot] : HX_EMPTY_SLOT;
+        deg += (uint32_t)__popcll(__ballot(cur[r] != HX_EMPTY_SLOT));
+    }
     for (uint32_t j = 0; j < k; j++) {
         const uint32_t nb = (uint32_t)(a.keys[lo + j] & HX_EDGE_ID_MASK);
-        const u64 hit = __ballot(cur == nb);
+        u64 hit = 0;
+#pragma unroll
+        for (int r = 0; r < RS; r++) hit |= __ballot(cur[r] == nb);
         if (hit == 0) continue;
         if (deg == 1) {  // the last edge stays
             if (lane == 0) {
@@ -2422,33 +2474,42 @@ hx_remove_kernel(const DevView v, const ConnectArgs a) {
             }
             continue;
         }
-        if (cur == nb) cur = HX_EMPTY_SLOT;
+#pragma unroll
+        for (int r = 0; r < RS; r++)
+            if (cur[r] == nb) cur[r] = HX_EMPTY_SLOT;
         deg--;
     }
     // compact: survivors to the front, every slot written by exactly one lane
-    const u64 hm = __ballot(cur != HX_EMPTY_SLOT);
-    const uint32_t pos = (uint32_t)__popcll(hm & ((1ull << lane) - 1));
-    const uint32_t left = (uint32_t)__popcll(hm);
-    if (cur != HX_EMPTY_SLOT) row[pos] = cur;
-    if ((uint32_t)lane >= left && (uint32_t)lane < S) row[lane] = HX_EMPTY_SLOT;
+    uint32_t before = 0;
+#pragma unroll
+    for (int r = 0; r < RS; r++) {
+        const u64 hm = __ballot(cur[r] != HX_EMPTY_SLOT);
+        if (cur[r] != HX_EMPTY_SLOT) row[before + (uint32_t)__popcll(hm & ((1ull << lane) - 1))] = cur[r];
+        before += (uint32_t)__popcll(hm);
+    }
+#pragma unroll
+    for (int r = 0; r < RS; r++) {
+        const uint32_t slot = 64u * r + (uint32_t)lane;
+        if (slot >= before && slot < S) row[slot] = HX_EMPTY_SLOT;
+    }
 }
 
-int launch_connect(const DevView &v, const ConnectArgs &a, hipStream_t stream) {
-    if (a.count == 0) return HNSW_OK;
+template <int RS>
+static int launch_connect_rs(const DevView &v, const ConnectArgs &a, hipStream_t stream) {
     const size_t yq_bytes =
         ((v.kind == HNSW_VEC_QUANT8 ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4) + 15) & ~15ull;
-    const size_t lds = 2 * 64 * 8 + yq_bytes;
+    const size_t lds = 2 * 64 * RS * 8 + yq_bytes;
     void (*kfn)(const DevView, const ConnectArgs);
     if (v.kind == HNSW_VEC_QUANT8)
-        kfn = v.dim == 100   ? hx_connect_kernel<HNSW_VEC_QUANT8, 100>
-              : v.dim == 128 ? hx_connect_kernel<HNSW_VEC_QUANT8, 128>
-              : v.dim == 256 ? hx_connect_kernel<HNSW_VEC_QUANT8, 256>
-              : v.dim == 768 ? hx_connect_kernel<HNSW_VEC_QUANT8, 768>
-                             : hx_connect_kernel<HNSW_VEC_QUANT8, 0>;
+        kfn = v.dim == 100   ? hx_connect_kernel<HNSW_VEC_QUANT8, 100, RS>
+              : v.dim == 128 ? hx_connect_kernel<HNSW_VEC_QUANT8, 128, RS>
+              : v.dim == 256 ? hx_connect_kernel<HNSW_VEC_QUANT8, 256, RS>
+              : v.dim == 768 ? hx_connect_kernel<HNSW_VEC_QUANT8, 768, RS>
+                             : hx_connect_kernel<HNSW_VEC_QUANT8, 0, RS>;
     else
-        kfn = v.dim == 100   ? hx_connect_kernel<HNSW_VEC_F32, 100>
-              : v.dim == 128 ? hx_connect_kernel<HNSW_VEC_F32, 128>
-                             : hx_connect_kernel<HNSW_VEC_F32, 0>;
+        kfn = v.dim == 100   ? hx_connect_kernel<HNSW_VEC_F32, 100, RS>
+              : v.dim == 128 ? hx_connect_kernel<HNSW_VEC_F32, 128, RS>
+                             : hx_connect_kernel<HNSW_VEC_F32, 0, RS>;
     hipLaunchKernelGGL(kfn, dim3(a.count), dim3(64), lds, stream, v, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -2458,9 +2519,48 @@ int launch_connect(const DevView &v, const ConnectArgs &a, hipStream_t stream) {
     return HNSW_OK;
 }
 
+// the wide-row instantiations (m = 64 / 128) exist for the dimension-generic loops only: one compile-time
+// dimension per row width would triple the build time of this file for shapes nobody has measured
+template <int RS>
+static int launch_connect_wide(const DevView &v, const ConnectArgs &a, hipStream_t stream) {
+    const size_t yq_bytes =
+        ((v.kind == HNSW_VEC_QUANT8 ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4) + 15) & ~15ull;
+    const size_t lds = 2 * 64 * RS * 8 + yq_bytes;
+    if (v.kind == HNSW_VEC_QUANT8)
+        hipLaunchKernelGGL((hx_connect_kernel<HNSW_VEC_QUANT8, 0, RS>), dim3(a.count), dim3(64), lds, stream, v, a);
+    else
+        hipLaunchKernelGGL((hx_connect_kernel<HNSW_VEC_F32, 0, RS>), dim3(a.count), dim3(64), lds, stream, v, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("connect kernel launch: %s", hipGetErrorString(e));
+        return HNSW_ERR_HIP;
+    }
+    return HNSW_OK;
+}
+
+int launch_connect(const DevView &v, const ConnectArgs &a, hipStream_t stream) {
+    if (a.count == 0) return HNSW_OK;
+    const uint32_t S = std::max(v.S0, v.S1);
+    if (S <= 64) return launch_connect_rs<1>(v, a, stream);
+    if (S <= 128) return launch_connect_wide<2>(v, a, stream);
+    if (S <= 256) return launch_connect_wide<4>(v, a, stream);
+    set_error("on-device build: adjacency rows of %u slots (m > 128)", S);
+    return HNSW_ERR_ARG;
+}
+
 int launch_remove(const DevView &v, const ConnectArgs &a, hipStream_t stream) {
     if (a.count == 0) return HNSW_OK;
-    hipLaunchKernelGGL(hx_remove_kernel, dim3(a.count), dim3(64), 0, stream, v, a);
+    const uint32_t S = std::max(v.S0, v.S1);
+    if (S <= 64)
+        hipLaunchKernelGGL(hx_remove_kernel<1>, dim3(a.count), dim3(64), 0, stream, v, a);
+    else if (S <= 128)
+        hipLaunchKernelGGL(hx_remove_kernel<2>, dim3(a.count), dim3(64), 0, stream, v, a);
+    else if (S <= 256)
+        hipLaunchKernelGGL(hx_remove_kernel<4>, dim3(a.count), dim3(64), 0, stream, v, a);
+    else {
+        set_error("on-device build: adjacency rows of %u slots (m > 128)", S);
+        return HNSW_ERR_ARG;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("remove kernel launch: %s", hipGetErrorString(e));

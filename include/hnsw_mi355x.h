@@ -113,7 +113,7 @@ int hnsw_insert_bulk_levels(hnsw_index *h, const float *rows, uint64_t n, uint32
  * the cap's nearest), a third pass drops the reverse edges of what was pruned (graph.rs:72-94, a
  * node's last edge stays).  The host graph is read back once at the end.  Points of one batch do not
  * see each other (like the racing threads of the reference's multi-threaded insert_bulk), so the graph
- * is judged by recall and invariants, not by identity with the sequential build.  Needs m <= 32 and
+ * is judged by recall and invariants, not by identity with the sequential build.  Needs m <= 128 and
  * ef_construction <= 512; nb_threads is used for the host-side parts (store, seed, read-back).
  * hnsw_set_option(h, "gpu_build", 2) routes hnsw_insert_bulk here; "gpu_build" = 1 selects the older
  * hybrid form (GPU searches, connect / prune on nb_threads host threads with the reference's locks). */

@@ -499,10 +499,14 @@ def test_device_build_extends_an_existing_index(build_inputs, mode):
     assert sum(len(set(a) & set(b)) for a, b in zip(ids.tolist(), truth.tolist())) / 640 > 0.97
 
 
-@pytest.mark.parametrize("kind,m,d", [(H.VEC_F32, 8, 33), (H.VEC_QUANT8, 24, 64), (H.VEC_QUANT8, 5, 100)])
+@pytest.mark.parametrize("kind,m,d", [(H.VEC_F32, 8, 33), (H.VEC_QUANT8, 24, 64), (H.VEC_QUANT8, 5, 100),
+                                      (H.VEC_QUANT8, 64, 100), (H.VEC_F32, 64, 48), (H.VEC_QUANT8, 128, 60),
+                                      (H.VEC_F32, 128, 100)])
 def test_device_connect_other_shapes(kind, m, d):
-    """device connect on other row strides (m = 5 -> 16 slots, 24 -> 64 slots) and the f32 kind"""
-    n = 12000
+    """device connect on other row strides (m = 5 -> 16 slots, 24 -> 64 slots), the f32 kind, and the M = 64 and
+    128 of the reference's own build benches (hnsw/benches/hnsw_benchmarks.rs:7): 128- and 256-slot layer-0 rows,
+    two and four registers per lane in hx_connect_kernel / hx_remove_kernel, up to 128 selected per layer"""
+    n = 12000 if m <= 32 else 8000
     vs = H.synth_rows(0, 0xC0FFEE + m, 0, n, d)
     qs = H.synth_rows(0, 0xBEEF + m, 0, 128, d)
     lv = O.draw_levels(n, m, 9)
@@ -527,6 +531,11 @@ def test_device_connect_other_shapes(kind, m, d):
     ids, _, _, _ = idx.search_batch(qs, 10, 96)
     rec = sum(len(set(a) & set(b)) for a, b in zip(ids.tolist(), truth.tolist())) / (len(qs) * 10)
     assert rec > 0.95, rec
+    if m > 32:  # recall equals the CPU build's (the reference's algorithm on the host threads)
+        cpu = H.HNSW.new(m, 48, d, kind).insert_bulk(vs, 8, False, levels=lv)
+        c_ids, _, _, _ = cpu.search_batch(qs, 10, 96)
+        c_rec = sum(len(set(a) & set(b)) for a, b in zip(c_ids.tolist(), truth.tolist())) / (len(qs) * 10)
+        assert rec >= c_rec - 0.01, (rec, c_rec)
     # and the search on it is still the reference's search
     orc = oracle_from_product(idx, vs, lv)
     assert_search_equal(idx.search_batch(qs, 10, 40), orc.search_batch(qs, 10, 40, nthreads=8), "device-connect")
