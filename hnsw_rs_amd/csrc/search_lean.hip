@@ -39,6 +39,7 @@
 #include "search_common.h"
 
 namespace hx {
+#include "coop_rows.inc"
 namespace {
 
 // block placement hints for the f32 kernel's pass (a taken branch costs a lone wave ~30 cycles of
@@ -538,11 +539,17 @@ template <int DS, class LT>
 __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
     constexpr int R = LT::NR;
     static_assert(DS % 4 == 0, "whole 16-byte pieces");
+    // rows of whole 128-byte lines (d = 128: the configs[3] dimension) are gathered cooperatively, eight lanes
+    // to a line, and summed by their owner lanes out of an LDS image (coop_rows.inc): no row registers, so the
+    // query's 128 values still fit beside the stage ring
+    constexpr bool COOP = coop_rows<HNSW_VEC_F32, DS>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const uint32_t q = a.qsel ? a.qsel[blockIdx.x] : blockIdx.x;
     const uint32_t hslots = 1u << a.slots_log2;
     u64 *perm = reinterpret_cast<u64 *>(smem + 4ull * hslots);
+    unsigned char *coop_img = reinterpret_cast<unsigned char *>(perm + 64 * R + 64);  // COOP: 4 KiB + 64 words
+    uint32_t *coop_ids = reinterpret_cast<uint32_t *>(coop_img + HX_COOP_IMG_BYTES);
     Visited vis;
     vis.tab = reinterpret_cast<uint32_t *>(smem);
 
@@ -555,7 +562,8 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
 
     // ---- the query: every lane holds all DS values (Point::new of a FullVec is the vector itself) ----
     const float *qp = a.Q + (size_t)q * DS;
-    float qv[DS];
+    QueryRegs<DS> qreg;
+    float(&qv)[DS] = qreg.v;
 #pragma unroll
     for (int e = 0; e < DS; e++) qv[e] = qp[e];
     {
@@ -569,6 +577,16 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
 #pragma unroll
     for (int e = 0; e < DS; e++) asm volatile("" : "+v"(qv[e]));  // pinned to VGPRs for the whole kernel
 
+    // distance of one row per wanting lane (every lane calls it: the cooperative form needs the whole wave)
+    auto dist_of = [&](uint32_t id, bool want) __attribute__((always_inline)) -> float {
+        if constexpr (COOP) {
+            return __builtin_sqrtf(f32_rows_coop<DS, HX_COOP_K, true>(reinterpret_cast<const uint8_t *>(a.rows), id, want,
+                                                                     qreg, coop_ids, coop_img, lane));
+        } else {
+            return row_dist<DS>(a.rows, id, want, qv);
+        }
+    };
+
     // ---- entry point (template.rs:316-319) ----
     u64 best = LK_INVALID;
     uint32_t cur = a.ep;
@@ -576,7 +594,7 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
         if (cur >= a.n_points) {
             status = HNSW_ERR_ARG;
         } else {
-            const float d0 = row_dist<DS>(a.rows, cur, lane == 0, qv);
+            const float d0 = dist_of(cur, lane == 0);
             const uint32_t bits = rdlane(__builtin_bit_cast(uint32_t, d0), 0);
             n_dist = 1;
             if (__builtin_bit_cast(float, bits) != __builtin_bit_cast(float, bits))
@@ -649,7 +667,7 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
                     if (HX_LIKELY(fm != 0)) {
                         uint32_t ubn = HX_EMPTY_SLOT;
                         if (fresh) ubn = a.upper_base[nb];  // in flight together with the vector row
-                        const float dist = row_dist<DS>(a.rows, nb, fresh, qv);
+                        const float dist = dist_of(nb, fresh);
                         const bool nan = fresh && dist != dist;
                         if (HX_UNLIKELY(__ballot(nan) != 0)) {
                             status = HNSW_ERR_NAN_INPUT;  // Dist::cmp would panic (dist.rs:32)
@@ -772,7 +790,15 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
             // paid a v_accvgpr_read per element and the kernel fell to one wave per SIMD.)  A lane of c
             // that turns out not to be fresh -- its id sat in a later bucket -- evaluates a distance for
             // nothing.
-            if (want_pre) {
+            if constexpr (COOP) {
+                // claims first (c's lanes), then one cooperative gather for c's fresh rows and the rows p's
+                // look called absent
+                const uint32_t old = vis.claim(nb, vb, ct);
+                fresh = old == HX_EMPTY_SLOT;
+                const bool pend = (ct != 4u) & !fresh;
+                if (HX_UNLIKELY(__ballot(pend) != 0)) fresh = vis.finish(nb, vb, ct, pend, fresh);
+                dist = dist_of(nb, upper ? want_pre : fresh);
+            } else if (want_pre) {
                 const uint4 *src = reinterpret_cast<const uint4 *>(a.rows + (size_t)nb * DS);
                 uint4 w[DS / 4];
 #pragma unroll
@@ -1296,7 +1322,8 @@ int launch_lean_q8(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
 template <int DS, class LT>
 int launch_lean_one(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
     constexpr int R = LT::NR;
-    const size_t lds = (4ull << a.slots_log2) + (64ull * R + 64) * 8;
+    const size_t lds = (4ull << a.slots_log2) + (64ull * R + 64) * 8 +
+                       (coop_rows<HNSW_VEC_F32, DS>() ? HX_COOP_IMG_BYTES + 256 : 0);
     auto kern = hx_lean_f32_kernel<DS, LT>;
     if (lds > 160 * 1024) {
         set_error("search needs %zu bytes of LDS (> 160 KiB)", lds);
@@ -1327,7 +1354,9 @@ bool lean_applicable(const DevView &v, const SearchArgs &a, uint32_t ef_max) {
     static const bool enabled = !(getenv("HNSW_MI355X_LEAN") && atoi(getenv("HNSW_MI355X_LEAN")) == 0);
     if (!enabled) return false;
     static const bool q8_enabled = !(getenv("HNSW_MI355X_LEAN_Q8") && atoi(getenv("HNSW_MI355X_LEAN_Q8")) == 0);
-    const bool f32_ok = v.kind == HNSW_VEC_F32 && v.dim == 100 && v.row_stride == 400;
+    static const bool coop128 = !(getenv("HNSW_MI355X_LEAN_128") && atoi(getenv("HNSW_MI355X_LEAN_128")) == 0);
+    const bool f32_ok = v.kind == HNSW_VEC_F32 && ((v.dim == 100 && v.row_stride == 400) ||
+                                                     (coop128 && v.dim == 128 && v.row_stride == 512));
     const bool q8_ok = q8_enabled && v.kind == HNSW_VEC_QUANT8 && v.dim == 100 && v.row_stride == 128 && v.half_bytes == 64;
     if (!f32_ok && !q8_ok) return false;
     if (a.entries != nullptr || a.layer_lo != 0 || a.layer_hi != (int32_t)v.nb_layers - 1) return false;
@@ -1365,6 +1394,10 @@ int launch_lean(const DevView &v, const SearchArgs &s, uint32_t nblocks, uint32_
         if (a.ef <= 64) return launch_lean_q8<Lst<1>>(a, nblocks, stream);
         if (interleaved) return launch_lean_q8<Lst<2>>(a, nblocks, stream);
         return launch_lean_q8<LstHT>(a, nblocks, stream);
+    }
+    if (v.dim == 128) {  // whole-line rows: the cooperative gather (HNSW_MI355X_LEAN_128=0: the generic kernel, for A/B runs)
+        if (a.ef <= 64) return launch_lean_one<128, Lst<1>>(a, nblocks, stream);
+        return launch_lean_one<128, LstHT>(a, nblocks, stream);
     }
     if (a.ef <= 64) return launch_lean_one<100, Lst<1>>(a, nblocks, stream);
     if (interleaved) return launch_lean_one<100, Lst<2>>(a, nblocks, stream);

@@ -68,8 +68,11 @@ def test_the_generic_f32_kernel_still_agrees(f32_100d):
 def test_128d(kind):
     """configs[3] dimension"""
     idx, orc, qs = device_built(20000, 128, 16, kind)
-    for ef in (64, 128):
+    # f32: ef <= 128 runs the lean kernel with the cooperative row gather (one list register up to 64, head +
+    # tail above), 200 the generic kernel; n = 100 reaches into the tail register
+    for ef in (1, 10, 64, 65, 100, 128, 200):
         assert_search_equal(idx.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=8), "128d ef=%d" % ef)
+    assert_search_equal(idx.search_batch(qs[:64], 100, 120), orc.search_batch(qs[:64], 100, 120, nthreads=8), "128d n=100")
 
 
 @pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])

@@ -31,9 +31,10 @@ def test_lean_kernels_fit_two_waves_per_simd_without_agprs_or_scratch(tmp_path):
         if m and cur is not None:
             cur[m.group(1).strip()] = int(m.group(2))
     timed = {k: v for k, v in kernels.items() if "hx_lean_f32_kernel" in k or "hx_lean_q8_kernel" in k}
-    assert len(timed) == 6, sorted(kernels)  # f32 and quant8: one register, head + tail, interleaved two (A/B)
+    # f32 100d and quant8: one register, head + tail, interleaved two (A/B); f32 128d (cooperative gather): one register, head + tail
+    assert len(timed) == 8, sorted(kernels)
     for name, r in timed.items():
         assert r.get("AGPRs", 0) == 0, (name, r)
         assert r.get("ScratchSize", 0) == 0 and r.get("VGPRs Spill", 0) == 0, (name, r)
         assert r.get("Occupancy", 0) >= 2, (name, r)
-        assert r.get("VGPRs", 999) <= 240, (name, r)
+        assert r.get("VGPRs", 999) <= 248, (name, r)  # two waves per SIMD need <= 256 allocated
