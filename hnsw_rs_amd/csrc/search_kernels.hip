@@ -741,6 +741,12 @@ __device__ __forceinline__ bool visited_insert(uint32_t *tab, uint32_t hmask, ui
     }
 }
 
+// bytes of the region the merge buffer shares with the cooperative gather's image (4 KiB + 64 rank words)
+template <int KIND, int DS, int R>
+__host__ __device__ constexpr uint32_t scratch_region_bytes() {
+    return coop_rows<KIND, DS>() && 64u * R * 8u < HX_COOP_IMG_BYTES + 256u ? (uint32_t)HX_COOP_IMG_BYTES + 256u : 64u * R * 8u;
+}
+
 template <int KIND, int P, int DS, int R, bool FAT>
 __global__ void __launch_bounds__(64)
 hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2) {
@@ -750,13 +756,19 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
     uint32_t *htab = reinterpret_cast<uint32_t *>(smem);
     const uint32_t hslots = 1u << slots_log2, hmask = hslots - 1;
     u64 *perm = reinterpret_cast<u64 *>(smem + 4ull * hslots);
-    float *yq = reinterpret_cast<float *>(perm + 64 * R);
+    // the merge's permutation buffer (64 R keys) and the cooperative gather's stage image + rank words are
+    // never live together (a distance pass ends before its merge starts), so they share one region: with a
+    // 32-KiB visited table the wave stays within a quarter of the CU's LDS for every list width up to 512
+    constexpr uint32_t PERM_BYTES = scratch_region_bytes<KIND, DS, R>();
+    float *yq = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(perm) + PERM_BYTES);
     const uint32_t vis_limit = hslots - (hslots >> 2);  // 75 % load at most
     // FAT: two 64 x 16 x P byte buffers for the prefetched block (after yq, 16-byte aligned)
     const uint32_t yq_bytes =
         ((KIND == HNSW_VEC_QUANT8 ? 2u * (v.half_bytes - 8) * 4u : v.dim * 4u) + 15u) & ~15u;
     unsigned char *spec_buf = reinterpret_cast<unsigned char *>(yq) + yq_bytes;
-    const uint32_t spec_lds = __builtin_amdgcn_groupstaticsize() + 4u * hslots + 64u * R * 8u + yq_bytes;
+    const uint32_t spec_lds = __builtin_amdgcn_groupstaticsize() + 4u * hslots + PERM_BYTES + yq_bytes;
+    unsigned char *coop_img = reinterpret_cast<unsigned char *>(perm);
+    uint32_t *coop_ids = reinterpret_cast<uint32_t *>(coop_img + HX_COOP_IMG_BYTES);
 
     constexpr int LPC = (KIND == HNSW_VEC_QUANT8) ? 2 : 1;  // lanes per candidate
     constexpr int CHUNK = 64 / LPC;                         // adjacency slots per pass
@@ -833,8 +845,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
             float sm = 0.0f;
             if constexpr (coop_rows<KIND, DS>()) {
                 // whole-line rows: eight lanes to a 128-byte line, owners sum out of an LDS image
-                sm = f32_rows_coop<(DS > 0 ? DS : 32), HX_COOP_K>(v.rows, id, active, yq,
-                                                                 reinterpret_cast<uint32_t *>(perm), spec_buf, lane);
+                sm = f32_rows_coop<(DS > 0 ? DS : 32), HX_COOP_K>(v.rows, id, active, yq, coop_ids, coop_img, lane);
             } else if (active) {
                 const uint4 *src = reinterpret_cast<const uint4 *>(v.rows + (size_t)id * v.row_stride);
                 if constexpr (coop_rows<KIND, DS>()) {
@@ -2611,9 +2622,8 @@ static int launch_one(const DevView &v, const SearchArgs &a, uint32_t nblocks, u
                       hipStream_t stream) {
     const size_t yq_bytes =
         (KIND == HNSW_VEC_QUANT8) ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4;
-    size_t lds = (4ull << slots_log2) + 64ull * R * 8 + ((yq_bytes + 15) & ~15ull);
+    size_t lds = (4ull << slots_log2) + scratch_region_bytes<KIND, DS, R>() + ((yq_bytes + 15) & ~15ull);
     if (FAT) lds += 2ull * 1024 * (P > 0 ? P : 1);
-    if (coop_rows<KIND, DS>()) lds += HX_COOP_IMG_BYTES;  // the stage image of f32_rows_coop (rank -> id words live in perm)
     auto kern = hx_search_kernel<KIND, P, DS, R, FAT>;
     if (lds > 160 * 1024) {
         set_error("search needs %zu bytes of LDS (> 160 KiB)", lds);
