@@ -2070,39 +2070,20 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
 #pragma unroll
         for (int r = 0; r < R; r++) wl.L[r] &= KEY_MASK;  // the flag now means "rejected"
         uint32_t cursor = 0;
-        while (ns < m && status == HNSW_OK) {
-            int pos = -1;
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const uint32_t idx = 64u * r + lane;
-                const u64 mk = __ballot(idx >= cursor && idx < n_c && (wl.L[r] & KEY_EXPANDED) == 0);
-                if (pos < 0 && mk) pos = 64 * r + (__ffsll((long long)mk) - 1);
-            }
-            if (pos < 0) break;  // every candidate was popped
-            u64 sk_sel = 0;
-#pragma unroll
-            for (int r = 0; r < R; r++)
-                if ((pos >> 6) == r) {
-                    sk_sel = readlane64(wl.L[r], pos & 63);
-                    if (lane == (pos & 63)) selbits |= 1u << r;
-                }
-            if (lane == 0) selk[ns] = sk_sel;
-            ns++;
-            cursor = (uint32_t)pos + 1;
-            wave_fence();
-            if (ns >= m || cursor >= n_c) continue;  // nothing left to decide
-            const uint32_t sid = (uint32_t)sk_sel;
-            stage_row<KIND>(v, sid, yqe, lane);
-            // (a rolled loop over the list registers with static selects: one copy of the distance
-            // code instead of R x LPC, and the list stays in registers)
+        // One sweep: the staged selected point (yqe, id sid) against the open candidates at positions [lo, hi):
+        // those it dominates -- (d(s, e), s) < (d(e, p), e) -- are marked rejected.
+        // (a rolled loop over the list registers with static selects: one copy of the distance
+        // code instead of R x LPC, and the list stays in registers)
+        auto sweep = [&](uint32_t sid, uint32_t lo, uint32_t hi) __attribute__((always_inline)) {
 #pragma unroll 1
             for (int rr = 0; rr < R; rr++) {
+                if (64u * rr + 64u <= lo || 64u * rr >= hi) continue;
                 u64 mine = KEY_INVALID;
 #pragma unroll
                 for (int r = 0; r < R; r++)
                     if (r == rr) mine = wl.L[r];
                 const uint32_t idx = 64u * rr + lane;
-                const bool open = idx >= cursor && idx < n_c && (mine & KEY_EXPANDED) == 0;
+                const bool open = idx >= lo && idx < hi && (mine & KEY_EXPANDED) == 0;
                 if (__ballot(open) == 0) continue;
                 const uint32_t my_id = (uint32_t)mine, my_db = (uint32_t)(mine >> 32);
                 bool mark = false;
@@ -2129,6 +2110,50 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
                 for (int r = 0; r < R; r++)
                     if (r == rr && mark) wl.L[r] |= KEY_EXPANDED;
             }
+        };
+        // The candidate set holds up to 512 entries but m selections usually come out of the first hundred:
+        // a selected point sweeps only the WINDOW [0, win_end) of candidates; when the window holds nothing
+        // unpopped and fewer than m are selected, it grows by 64 and the points selected so far sweep the new
+        // part first.  Every candidate is still judged against every point selected before it is popped, so the
+        // selection is the one the whole-set sweep made (round 2: every selection swept all 512 -- eight distance
+        // passes per selection, most of them for candidates that are never reached).
+        uint32_t win_end = min(n_c, 128u);
+        while (ns < m && status == HNSW_OK) {
+            int pos = -1;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint32_t idx = 64u * r + lane;
+                const u64 mk = __ballot(idx >= cursor && idx < win_end && (wl.L[r] & KEY_EXPANDED) == 0);
+                if (pos < 0 && mk) pos = 64 * r + (__ffsll((long long)mk) - 1);
+            }
+            if (pos < 0) {
+                if (win_end >= n_c) break;  // every candidate was popped
+                const uint32_t new_end = min(n_c, win_end + 64u);
+                for (uint32_t k2 = 0; k2 < ns && status == HNSW_OK; k2++) {  // catch up: the new part against the selected
+                    const uint32_t sid2 = (uint32_t)selk[k2];
+                    stage_row<KIND>(v, sid2, yqe, lane);
+                    sweep(sid2, win_end, new_end);
+                }
+                cursor = win_end;
+                win_end = new_end;
+                if (__ballot(status != HNSW_OK)) status = HNSW_ERR_NAN_INPUT;
+                continue;
+            }
+            u64 sk_sel = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if ((pos >> 6) == r) {
+                    sk_sel = readlane64(wl.L[r], pos & 63);
+                    if (lane == (pos & 63)) selbits |= 1u << r;
+                }
+            if (lane == 0) selk[ns] = sk_sel;
+            ns++;
+            cursor = (uint32_t)pos + 1;
+            wave_fence();
+            if (ns >= m || (cursor >= win_end && win_end >= n_c)) continue;  // nothing left to decide
+            const uint32_t sid = (uint32_t)sk_sel;
+            stage_row<KIND>(v, sid, yqe, lane);
+            sweep(sid, cursor, win_end);
             if (__ballot(status != HNSW_OK)) status = HNSW_ERR_NAN_INPUT;
         }
         // keep_pruned: fill up from the rejected candidates in ascending order (searcher.rs:141-146);

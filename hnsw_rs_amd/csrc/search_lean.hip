@@ -535,7 +535,12 @@ __device__ __forceinline__ float row_dist(const float *rows, uint32_t id, bool w
     return __builtin_sqrtf(s);
 }
 
-template <int DS, class LT>
+// CK: stages of the cooperative gather in flight (d = 128 only).  The query's 128 values, the stage ring and
+// both forms of the gather do not fit 256 registers with four stages: that build parks a few values in AGPRs
+// and runs one wave per SIMD -- right for launches of up to four waves per CU (4M x 128d, efSearch 64, batch
+// 1024: 0.256 ms against 0.264 ms with two stages), wrong for larger ones (8192 queries: 1.63 against 1.23 ms),
+// which take the two-stage build (252 registers, two waves per SIMD).
+template <int DS, class LT, int CK = 4>
 __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
     constexpr int R = LT::NR;
     static_assert(DS % 4 == 0, "whole 16-byte pieces");
@@ -580,8 +585,8 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
     // distance of one row per wanting lane (every lane calls it: the cooperative form needs the whole wave)
     auto dist_of = [&](uint32_t id, bool want) __attribute__((always_inline)) -> float {
         if constexpr (COOP) {
-            return __builtin_sqrtf(f32_rows_coop<DS, HX_COOP_K, true>(reinterpret_cast<const uint8_t *>(a.rows), id, want,
-                                                                     qreg, coop_ids, coop_img, lane));
+            return __builtin_sqrtf(f32_rows_coop<DS, CK, true, true>(reinterpret_cast<const uint8_t *>(a.rows), id, want, qreg,
+                                                                    coop_ids, coop_img, lane));
         } else {
             return row_dist<DS>(a.rows, id, want, qv);
         }
@@ -1319,12 +1324,12 @@ int launch_lean_q8(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
     return HNSW_OK;
 }
 
-template <int DS, class LT>
+template <int DS, class LT, int CK = 4>
 int launch_lean_one(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
     constexpr int R = LT::NR;
     const size_t lds = (4ull << a.slots_log2) + (64ull * R + 64) * 8 +
                        (coop_rows<HNSW_VEC_F32, DS>() ? HX_COOP_IMG_BYTES + 256 : 0);
-    auto kern = hx_lean_f32_kernel<DS, LT>;
+    auto kern = hx_lean_f32_kernel<DS, LT, CK>;
     if (lds > 160 * 1024) {
         set_error("search needs %zu bytes of LDS (> 160 KiB)", lds);
         return HNSW_ERR_ARG;
@@ -1396,8 +1401,16 @@ int launch_lean(const DevView &v, const SearchArgs &s, uint32_t nblocks, uint32_
         return launch_lean_q8<LstHT>(a, nblocks, stream);
     }
     if (v.dim == 128) {  // whole-line rows: the cooperative gather (HNSW_MI355X_LEAN_128=0: the generic kernel, for A/B runs)
-        if (a.ef <= 64) return launch_lean_one<128, Lst<1>>(a, nblocks, stream);
-        return launch_lean_one<128, LstHT>(a, nblocks, stream);
+        static const uint32_t n_cu = [] {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                cus = 256;
+            return (uint32_t)cus;
+        }();
+        const bool few = nblocks <= 4 * n_cu;  // at most one wave per SIMD: the four-stage build (see the kernel)
+        if (a.ef <= 64) return few ? launch_lean_one<128, Lst<1>, 4>(a, nblocks, stream) : launch_lean_one<128, Lst<1>, 2>(a, nblocks, stream);
+        return few ? launch_lean_one<128, LstHT, 4>(a, nblocks, stream) : launch_lean_one<128, LstHT, 2>(a, nblocks, stream);
     }
     if (a.ef <= 64) return launch_lean_one<100, Lst<1>>(a, nblocks, stream);
     if (interleaved) return launch_lean_one<100, Lst<2>>(a, nblocks, stream);

@@ -1,0 +1,64 @@
+#!/bin/bash
+# Profiling recipe for BASELINE configs[2] (10M x 768d f32, efSearch 128) on the GPU box (gpurun):
+#   bash scripts/profile_c2.sh r03
+# 1. the plain bench line; 2. rocprofv3 kernel trace + stats; 3. FETCH_SIZE and WRITE_SIZE in their own passes,
+# counters restricted to the search kernel (the build's tens of thousands of dispatches stay uninstrumented).
+# Output: gpurun_out/<tag>_c2/ ; `traffic_c2.json` holds the entry for profiles/traffic_latest.json.
+set -o pipefail
+TAG=${1:-r03}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/${TAG}_c2
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd $REPO
+python bench.py --config 2 2> $OUT/bench.err > $OUT/bench.json || { tail -5 $OUT/bench.err; exit 1; }
+P="--config 2 --steps 20 --warmup 4 --no-cpu-baseline --no-concurrent --no-extras --recall-queries 256"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $REPO/bench.py $P > $OUT/trace.json 2> $OUT/trace.err || { tail -5 $OUT/trace.err; exit 1; }
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "hx_search_kernel" --output-format csv -d $OUT/pmc_fetch -- python $REPO/bench.py $P > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || { tail -5 $OUT/pmc_fetch.err; exit 1; }
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "hx_search_kernel" --output-format csv -d $OUT/pmc_write -- python $REPO/bench.py $P > $OUT/pmc_write.json 2> $OUT/pmc_write.err || { tail -5 $OUT/pmc_write.err; exit 1; }
+cd $REPO
+python - <<PY > $OUT/summary.txt
+import csv, glob, json
+out = "$OUT"
+line = json.loads(open(out + "/trace.json").read().strip().splitlines()[-1])
+full = json.loads(open(out + "/bench.json").read().strip().splitlines()[-1])
+print("== bench line (python bench.py --config 2) ==")
+print(json.dumps(full))
+print()
+print("bench under rocprofv3: value %.0f q/s, kernel_ms %.5f, efSearch %d" % (line["value"], line["roofline"]["kernel_ms"], line["config"]["efSearch"]))
+st = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)
+if st:
+    print("-- rocprofv3 --kernel-trace --stats (kernel_stats.csv), first rows --")
+    for i, row in enumerate(csv.reader(open(st[0]))):
+        if i < 6: print(", ".join(row))
+tr = glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True)
+if tr:
+    rows = [r for r in csv.DictReader(open(tr[0])) if "hx_search_kernel" in r.get("Kernel_Name", "")]
+    names = {}
+    for r in rows: names[r["Kernel_Name"]] = names.get(r["Kernel_Name"], 0) + 1
+    timed = max(names, key=names.get)
+    rows = [r for r in rows if r["Kernel_Name"] == timed and r["Grid_Size"] == str(64 * line["config"]["batch_per_gpu"])]
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows][-20:]
+    r0 = rows[-1]
+    print("timed search-kernel dispatches: %d, duration us: min %.1f median %.1f mean %.1f max %.1f" % (len(durs), min(durs), sorted(durs)[len(durs) // 2], sum(durs) / len(durs), max(durs)))
+    print("kernel %s | VGPR_Count %s (rocprofv3's unit; the compiler's count is in tests/test_kernel_resources.py) SGPR %s LDS %s scratch %s" % (timed[:70], r0.get("VGPR_Count"), r0.get("SGPR_Count"), r0.get("LDS_Block_Size"), r0.get("Scratch_Size")))
+res = {}
+for cname, dname in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    f = glob.glob(out + "/%s/**/*counter_collection.csv" % dname, recursive=True)
+    if not f: continue
+    prow = [r for r in csv.DictReader(open(f[0])) if r.get("Counter_Name") == cname and r["Grid_Size"] == str(64 * line["config"]["batch_per_gpu"])]
+    pn = {}
+    for r in prow: pn[r["Kernel_Name"]] = pn.get(r["Kernel_Name"], 0) + 1
+    vals = [float(r["Counter_Value"]) for r in prow if r["Kernel_Name"] == max(pn, key=pn.get)][-20:]
+    res[cname] = sum(vals) / len(vals)
+    print("%s per timed search launch: mean %.1f KB (raw counter) over %d launches" % (cname, res[cname], len(vals)))
+if "FETCH_SIZE" in res:
+    fk, wk = res["FETCH_SIZE"], res.get("WRITE_SIZE", 0.0)
+    hbm = int((2 * fk + wk) * 1024)
+    alg = line["roofline"]["algorithmic_bytes_per_launch"]
+    print("HBM traffic per launch: read %.1f MB raw -> %.1f MB after the gfx950 x2 (calibrated on this access shape: profiles/r03_gather_shapes_fetch_size.txt), write %.2f MB; algorithmic %.1f MB; ratio %.2f" % (fk / 1024, 2 * fk / 1024, wk / 1024, alg / 1e6, hbm / alg))
+    a = line["config"]
+    json.dump({"workload": a["index_tag"], "ef": a["efSearch"], "batch": a["batch_per_gpu"], "fetch_size_kb_raw": fk, "write_size_kb": wk, "hbm_bytes_per_launch": hbm}, open(out + "/traffic_c2.json", "w"))
+PY
+cat $OUT/summary.txt | cut -c1-400

@@ -57,7 +57,7 @@ for kind in ("f32", "quant8"):
             print("timed search-kernel dispatches: %d, duration us: min %.1f median %.1f mean %.1f max %.1f" % (
                 len(durs), min(durs), sorted(durs)[len(durs) // 2], sum(durs) / len(durs), max(durs)))
             r0 = rows[-1]
-            print("kernel %s | VGPR %s SGPR %s LDS %s scratch %s" % (
+            print("kernel %s | VGPR_Count %s (rocprofv3 reports wave64 registers in units of two: x 2 = the allocation, which rounds the compiler's count of tests/test_kernel_resources.py up to a multiple of 8) SGPR %s LDS %s scratch %s" % (
                 r0.get("Kernel_Name", "")[:80], r0.get("VGPR_Count"), r0.get("SGPR_Count"),
                 r0.get("LDS_Block_Size"), r0.get("Scratch_Size")))
     res = {}
