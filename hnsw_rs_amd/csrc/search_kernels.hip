@@ -694,6 +694,22 @@ struct WaveList {
     }
 };
 
+// merge over the first RR registers of a wider list (every entry at 64 RR and beyond is invalid before and after)
+template <int RR, int R>
+__device__ __forceinline__ void merge_prefix(WaveList<R> &wl, u64 key, uint32_t ef, u64 *perm, int lane, u64 new_flag) {
+    static_assert(RR <= R, "prefix of the list");
+    WaveList<RR> t;
+#pragma unroll
+    for (int r = 0; r < RR; r++) t.L[r] = wl.L[r];
+    t.n_cur = wl.n_cur;
+    t.last_key = wl.last_key;
+    t.merge(key, ef, perm, lane, new_flag);
+#pragma unroll
+    for (int r = 0; r < RR; r++) wl.L[r] = t.L[r];
+    wl.n_cur = t.n_cur;
+    wl.last_key = t.last_key;
+}
+
 // LDS visited table (IntSet::insert, results.rs:101-103): open addressing over BUCKETS of four
 // 32-bit slots.  One ds_read_b128 fetches the home bucket, the four compares run in registers and
 // a single ds_cmpst claims the first empty slot, so an insert is two LDS round trips whatever the
@@ -1979,7 +1995,19 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
             if (!nan) key = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | id;
         }
         if (__ballot(nan)) status = HNSW_ERR_NAN_INPUT;
-        wl.merge(key, ef_l, perm, lane, new_flag);
+        // The list has eight registers for the heuristic's 512 candidates, and a merge pays its rank / scatter
+        // work per register.  Entries beyond min(n_cur + batch, ef) cannot exist before or after this merge, so it
+        // runs over the registers that can hold something: one for the searches (ef = 1 above the point's level,
+        // ef_cons <= 64 below), two or four while the candidate set is filling.
+        const uint32_t reach = min(wl.n_cur + (uint32_t)__popcll(fm), ef_l);
+        if (reach <= 64u)
+            merge_prefix<1>(wl, key, ef_l, perm, lane, new_flag);
+        else if (reach <= 128u)
+            merge_prefix<2>(wl, key, ef_l, perm, lane, new_flag);
+        else if (reach <= 256u)
+            merge_prefix<4>(wl, key, ef_l, perm, lane, new_flag);
+        else
+            wl.merge(key, ef_l, perm, lane, new_flag);
     };
     // expand every unexpanded entry of the list on `layer` (search_layer's loop, searcher.rs:35-95)
     auto expand_all = [&](int layer, uint32_t ef_l, u64 new_flag) __attribute__((always_inline)) {
