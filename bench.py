@@ -52,7 +52,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 def kernel_sources_sha16():
     import hashlib
     h = hashlib.sha256()
-    for f in ("search_kernels.hip", "search_lean.hip", "search_common.h", "device_index.h"):
+    for f in ("search_kernels.hip", "search_lean.hip", "coop_rows.inc", "search_common.h", "device_index.h"):
         h.update(open(os.path.join(ROOT, "hnsw_rs_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 EF_LADDER = (64, 68, 72, 76, 80, 88, 96, 112, 128, 160, 192, 256)

@@ -1314,8 +1314,18 @@ int hnsw_brute_force_fast(hnsw_index *h, const float *Q, uint64_t nq, uint32_t k
         set_error("the MFMA scan serves f32 rows whose dimension is a multiple of 4");
         return HNSW_ERR_ARG;
     }
+    // A NaN in a query makes every screen score NaN, and `score < threshold` is false for NaN: the screen would
+    // keep nothing and the call would return padding ids with status OK where the exact scan reports
+    // HNSW_ERR_NAN_INPUT (stored rows cannot hold one: insert rejects them)
+    for (uint64_t i = 0; i < nq * (uint64_t)v.dim; i++)
+        if (Q[i] != Q[i]) {
+            set_error("query %llu: NaN in the query", (unsigned long long)(i / v.dim));
+            return HNSW_ERR_NAN_INPUT;
+        }
     const uint64_t batch = 2048;  // queries per launch: 64 tiles of 32
-    const uint32_t ntile_max = (uint32_t)(batch / 32);
+    // (buffers sized for the tiles a launch really has: a 32-query call on a multi-million-point index has one
+    // tile and up to 768 segments, not 64 tiles of them)
+    const uint32_t ntile_max = (uint32_t)((std::min(batch, nq) + 31) / 32);
     // enough workgroups for the chip (256 CUs, one 98-KB query tile each at d = 768) without cutting the
     // points into segments shorter than a few tiles per wave
     // about 768 workgroups per launch (256 CUs, up to three 32-query tiles of a small dimension each), but

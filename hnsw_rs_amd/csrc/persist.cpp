@@ -298,10 +298,12 @@ int load_index(const std::string &dir, std::unique_ptr<HostIndex> *out) {
         set_error("params: entry point %u is not a node of the top layer", p.ep);
         return HNSW_ERR_IO;
     }
-    if (p.mmax < p.m || p.mmax0 < p.m || p.mmax > 65535 || p.mmax0 > 65535 || p.ef_cons == 0) {
-        set_error("params: mmax %llu / mmax0 %llu / ef_cons %llu are inconsistent with m %llu",
-                  (unsigned long long)p.mmax, (unsigned long long)p.mmax0, (unsigned long long)p.ef_cons,
-                  (unsigned long long)p.m);
+    // Params::from accepts any mmax / mmax0, also below m (params.rs:44-62: they are only read by
+    // assert_param_compliance); refused here is only what would mis-size a device structure: a cap beyond the
+    // layer files' 16-bit row width, and ef_cons = 0 (the build searches with it)
+    if (p.mmax > 65535 || p.mmax0 > 65535 || p.ef_cons == 0) {
+        set_error("params: mmax %llu / mmax0 %llu beyond the 16-bit row width of the layer files, or ef_cons %llu = 0",
+                  (unsigned long long)p.mmax, (unsigned long long)p.mmax0, (unsigned long long)p.ef_cons);
         return HNSW_ERR_IO;
     }
     idx->version = 1;

@@ -92,7 +92,7 @@ import hashlib
 import subprocess
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 hh = hashlib.sha256()
-for f in ("search_kernels.hip", "search_lean.hip", "search_common.h", "device_index.h"):
+for f in ("search_kernels.hip", "search_lean.hip", "coop_rows.inc", "search_common.h", "device_index.h"):
     hh.update(open(os.path.join(root, "hnsw_rs_amd", "csrc", f), "rb").read())
 try:
     commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True,
