@@ -752,14 +752,19 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
             a.req_keys = dKeyA.as<uint64_t>();
             a.req_vals = dValA.as<uint32_t>();
             a.req_count = cnt + 0;
+            a.req_fail_base = cnt + 4;
             a.req_cap = REQ_CAP;
+            HIP_TRY(hipMemset(cnt + 4, 0xFF, 4));  // no reservation has failed yet
             rc = hx::launch_insert(v, a, (uint32_t)nb, nullptr);
             if (rc != HNSW_OK) return rc;
-            HIP_TRY(hipMemcpy(counts, dCnt.p, 16, hipMemcpyDeviceToHost));  // synchronises
+            uint32_t c5[5];
+            HIP_TRY(hipMemcpy(c5, dCnt.p, 20, hipMemcpyDeviceToHost));  // synchronises
+            memcpy(counts, c5, 16);
             HIP_TRY(hipMemcpy(o_st.data(), dStatus.p, nb * 4, hipMemcpyDeviceToHost));
             for (size_t i = 0; i < nb; i++)
                 if (o_st[i] != HNSW_OK) failed.push_back(batch[i]);  // filed nothing; CPU path after the build
-            nreq = counts[0];  // reservations that fit, nothing else (hx_insert_kernel)
+            // the records written: everything reserved, or the prefix below the first reservation that did not fit
+            nreq = std::min(c5[0], c5[4]);
             if (nreq > REQ_CAP) {
                 set_error("on-device build: record counter %u beyond the capacity %u", nreq, REQ_CAP);
                 return HNSW_ERR_OVERFLOW;
@@ -771,9 +776,11 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
             uint32_t *fail_ids = reinterpret_cast<uint32_t *>(slot + SH_HEADER);
             const size_t o_keys = SH_HEADER + SH_FAILCAP * 4, o_vals = o_keys + (size_t)SLOT_REC * 8;
             HIP_TRY(hipMemset(slot, 0, SH_HEADER));
+            HIP_TRY(hipMemset(hdr + 2, 0xFF, 4));  // header: [count, nfail, first failing base, ...]
             a.req_keys = reinterpret_cast<uint64_t *>(slot + o_keys);
             a.req_vals = reinterpret_cast<uint32_t *>(slot + o_vals);
             a.req_count = hdr;
+            a.req_fail_base = hdr + 2;
             a.req_cap = SLOT_REC;
             a.emit_own = 1;
             rc = hx::launch_insert(v, a, (uint32_t)nb, nullptr);
@@ -787,6 +794,12 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
                 return HNSW_ERR_OVERFLOW;
             }
             const uint32_t nf = (uint32_t)myfail.size();
+            {  // the count the other ranks read: the records really written (see hx_insert_kernel's reservation)
+                uint32_t h3[3];
+                HIP_TRY(hipMemcpy(h3, hdr, 12, hipMemcpyDeviceToHost));
+                const uint32_t written = std::min(h3[0], h3[2]);
+                if (written != h3[0]) HIP_TRY(hipMemcpy(hdr, &written, 4, hipMemcpyHostToDevice));
+            }
             HIP_TRY(hipMemcpy(hdr + 1, &nf, 4, hipMemcpyHostToDevice));
             if (nf) HIP_TRY(hipMemcpy(fail_ids, myfail.data(), nf * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipDeviceSynchronize());

@@ -90,7 +90,9 @@ struct InsertArgs {
     uint32_t *adj0_mut, *adj_up_mut;
     uint64_t *req_keys;         // hx_edge_key(layer, target, source)
     uint32_t *req_vals;         // bits of d(source, target)
-    uint32_t *req_count;
+    uint32_t *req_count;        // records reserved (may pass req_cap: see req_fail_base)
+    uint32_t *req_fail_base;    // smallest base of a reservation that did not fit (host: 0xFFFFFFFF before the launch);
+                                // the records written are [0, min(*req_count, *req_fail_base))
     uint32_t req_cap;
     uint32_t emit_own;          // 1: no own-row writes, records in both directions (sharded build)
 };
