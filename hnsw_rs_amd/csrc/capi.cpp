@@ -336,6 +336,23 @@ int search_host(hnsw_index *h, hx::SearchArgs a_host, const float *Q, uint64_t n
 // of one batch do not see each other, like the racing threads of the reference's own multi-threaded
 // insert_bulk.  The result is a valid HNSW graph judged by recall, not by identity.
 // ---------------------------------------------------------------------------------------------
+// Insertion order of the reference: layers top-down, ids ascending inside a level (template.rs:403-416); the
+// entry point is already in.  Levels are bytes: one counting pass instead of a sort of tens of millions of ids.
+std::vector<hx::NodeID> insertion_order(const hx::HostIndex &host, const std::vector<hx::NodeID> &ids) {
+    size_t count[257] = {0};
+    for (hx::NodeID id : ids)
+        if (id != host.params.ep) count[host.levels[id]]++;
+    size_t start[256], at = 0;
+    for (int l = 255; l >= 0; l--) {
+        start[l] = at;
+        at += count[l];
+    }
+    std::vector<hx::NodeID> order(at);
+    for (hx::NodeID id : ids)
+        if (id != host.params.ep) order[start[host.levels[id]]++] = id;
+    return order;
+}
+
 int gpu_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads, int verbose,
                     const uint8_t *levels) {
     using hx::NodeID;
@@ -351,12 +368,7 @@ int gpu_insert_bulk(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_th
     if (rc != HNSW_OK) return rc;
     host.prepare_build();
     // insertion order of the reference: layers top-down, ids ascending inside a level (template.rs:403-416)
-    std::vector<NodeID> order;
-    order.reserve(ids.size());
-    for (NodeID id : ids)
-        if (id != host.params.ep) order.push_back(id);
-    std::stable_sort(order.begin(), order.end(),
-                     [&](NodeID x, NodeID y) { return host.levels[x] > host.levels[y]; });
+    const std::vector<NodeID> order = insertion_order(host, ids);
 
     // ---- seed on the CPU: the first points must be inserted one after the other ----
     const uint64_t SEED = 2048;
@@ -636,18 +648,22 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     }
     const uint64_t n_before = host.len();
     std::vector<NodeID> ids;
+    const auto t_enter = std::chrono::steady_clock::now();
     int rc = host.store_points(rows, n, levels, &ids, nb_threads);
     if (rc != HNSW_OK) return rc;
+    const auto t_stored = std::chrono::steady_clock::now();
     host.prepare_build();
-    std::vector<NodeID> order;
-    order.reserve(ids.size());
-    for (NodeID id : ids)
-        if (id != host.params.ep) order.push_back(id);
-    std::stable_sort(order.begin(), order.end(),
-                     [&](NodeID x, NodeID y) { return host.levels[x] > host.levels[y]; });
+    const auto t_prep = std::chrono::steady_clock::now();
+    const std::vector<NodeID> order = insertion_order(host, ids);
+    const auto t_ordered = std::chrono::steady_clock::now();
     const uint64_t SEED = 2048;
     size_t pos = 0;
     std::unique_ptr<hx::Inserter, void (*)(hx::Inserter *)> ins(hx::new_inserter(host.len()), hx::free_inserter);
+    if (verbose)
+        fprintf(stderr, "host phases before the seed: store_points %.2f s, locks %.2f s, order %.2f s, inserter %.2f s\n",
+                std::chrono::duration<double>(t_stored - t_enter).count(), std::chrono::duration<double>(t_prep - t_stored).count(),
+                std::chrono::duration<double>(t_ordered - t_prep).count(),
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ordered).count());
     if (n_before < SEED) {
         const size_t take = std::min<size_t>(order.size(), SEED - n_before);
         for (size_t i = 0; i < take; i++) {
@@ -667,6 +683,7 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     const auto t_start = std::chrono::steady_clock::now();
     std::vector<uint64_t> restore;
     clamp_rows_to_cap(host, &restore);
+    const auto t_clamped = std::chrono::steady_clock::now();
     const int saved_inline = h->dev.inline_rows;
     h->dev.inline_rows = 0;
     h->dev.release();
@@ -675,6 +692,7 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     if (rc != HNSW_OK) return rc;
     h->device = h->dev.device;
     HIP_TRY(hipSetDevice(h->dev.device));
+    const auto t_uploaded = std::chrono::steady_clock::now();
     hx::DevView v = h->dev.view;
     const uint32_t m = (uint32_t)host.params.m, L = host.nb_layers();
     const uint32_t BMAX = SH_BCAP;
@@ -723,8 +741,9 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     std::vector<NodeID> failed;
     uint64_t connected = n_before + pos;
     double t_ins = 0, t_conn = 0;
-    size_t n_batches = 0, n_req = 0, n_rem = 0;
+    size_t n_batches = 0, n_req = 0, n_rem = 0, n_again = 0;
     uint32_t counts[4];
+    const auto t_loop0 = std::chrono::steady_clock::now();
 
     while (pos < order.size()) {
         const size_t B = std::min<size_t>(order.size() - pos,
@@ -755,14 +774,35 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
             a.req_fail_base = cnt + 4;
             a.req_cap = REQ_CAP;
             HIP_TRY(hipMemset(cnt + 4, 0xFF, 4));  // no reservation has failed yet
-            rc = hx::launch_insert(v, a, (uint32_t)nb, nullptr);
+            const int first_adjust = hx::insert_table_first_adjust(v, a);
+            rc = hx::launch_insert(v, a, (uint32_t)nb, nullptr, first_adjust);
             if (rc != HNSW_OK) return rc;
             uint32_t c5[5];
             HIP_TRY(hipMemcpy(c5, dCnt.p, 20, hipMemcpyDeviceToHost));  // synchronises
-            memcpy(counts, c5, 16);
             HIP_TRY(hipMemcpy(o_st.data(), dStatus.p, nb * 4, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < nb; i++)
-                if (o_st[i] != HNSW_OK) failed.push_back(batch[i]);  // filed nothing; CPU path after the build
+            // A point that filled its visited table filed nothing: it runs again in this batch with a larger
+            // table (the result of a search does not depend on the table's size, and the points of a batch do
+            // not see each other anyway).  Not when a reservation failed: then the counter is past the capacity.
+            std::vector<NodeID> again;
+            for (size_t i = 0; i < nb; i++) {
+                if (o_st[i] == HNSW_OK) continue;
+                if (o_st[i] == HNSW_ERR_OVERFLOW && c5[4] == UINT32_MAX) {
+                    again.push_back(batch[i]);
+                } else {
+                    failed.push_back(batch[i]);  // filed nothing; CPU path after the build
+                }
+            }
+            if (!again.empty()) {
+                HIP_TRY(hipMemcpy(dIds.p, again.data(), again.size() * 4, hipMemcpyHostToDevice));
+                rc = hx::launch_insert(v, a, (uint32_t)again.size(), nullptr, std::max(first_adjust, 0) + 1);
+                if (rc != HNSW_OK) return rc;
+                HIP_TRY(hipMemcpy(c5, dCnt.p, 20, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(o_st.data(), dStatus.p, again.size() * 4, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < again.size(); i++)
+                    if (o_st[i] != HNSW_OK) failed.push_back(again[i]);
+                n_again += again.size();
+            }
+            memcpy(counts, c5, 16);
             // the records written: everything reserved, or the prefix below the first reservation that did not fit
             nreq = std::min(c5[0], c5[4]);
             if (nreq > REQ_CAP) {
@@ -783,12 +823,30 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
             a.req_fail_base = hdr + 2;
             a.req_cap = SLOT_REC;
             a.emit_own = 1;
-            rc = hx::launch_insert(v, a, (uint32_t)nb, nullptr);
+            const int first_adjust = hx::insert_table_first_adjust(v, a);
+            rc = hx::launch_insert(v, a, (uint32_t)nb, nullptr, first_adjust);
             if (rc != HNSW_OK) return rc;
             if (nb) HIP_TRY(hipMemcpy(o_st.data(), dStatus.p, nb * 4, hipMemcpyDeviceToHost));  // synchronises
-            std::vector<uint32_t> myfail;
-            for (size_t i = 0; i < nb; i++)
-                if (o_st[i] != HNSW_OK) myfail.push_back(batch[s_lo + i]);
+            std::vector<uint32_t> myfail, again;
+            uint32_t h3a[3] = {0, 0, UINT32_MAX};
+            if (nb) HIP_TRY(hipMemcpy(h3a, hdr, 12, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < nb; i++) {
+                if (o_st[i] == HNSW_OK) continue;
+                if (o_st[i] == HNSW_ERR_OVERFLOW && h3a[2] == UINT32_MAX) {
+                    again.push_back(batch[s_lo + i]);  // filled its visited table: once more with a larger one
+                } else {
+                    myfail.push_back(batch[s_lo + i]);
+                }
+            }
+            if (!again.empty()) {
+                HIP_TRY(hipMemcpy(dIds.p, again.data(), again.size() * 4, hipMemcpyHostToDevice));
+                rc = hx::launch_insert(v, a, (uint32_t)again.size(), nullptr, std::max(first_adjust, 0) + 1);
+                if (rc != HNSW_OK) return rc;
+                HIP_TRY(hipMemcpy(o_st.data(), dStatus.p, again.size() * 4, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < again.size(); i++)
+                    if (o_st[i] != HNSW_OK) myfail.push_back(again[i]);
+                n_again += again.size();
+            }
             if (myfail.size() > SH_FAILCAP) {
                 set_error("sharded build: %zu points of one batch failed on the device", myfail.size());
                 return HNSW_ERR_OVERFLOW;
@@ -921,15 +979,19 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     // an edge x -> nb that stayed because it was x's last one: restore nb -> x (graph.rs:85-94 keeps both)
     refusals.insert(refusals.end(), restore.begin(), restore.end());
     const uint64_t id_mask = (1ull << hx::HX_EDGE_ID_BITS) - 1;
+    std::vector<uint64_t> touched;  // rows the host changes after the read-back: (layer << 32) | id
     for (uint64_t key : refusals) {
         const uint32_t layer = (uint32_t)(key >> (2 * hx::HX_EDGE_ID_BITS));
         const NodeID x = (NodeID)((key >> hx::HX_EDGE_ID_BITS) & id_mask), nb = (NodeID)(key & id_mask);
         std::vector<NodeID> &row = host.row(layer, nb);
         const std::vector<NodeID> &back = host.row(layer, x);
         if (std::find(back.begin(), back.end(), nb) != back.end() &&
-            std::find(row.begin(), row.end(), x) == row.end())
+            std::find(row.begin(), row.end(), x) == row.end()) {
             row.push_back(x);
+            touched.push_back(((uint64_t)layer << 32) | nb);
+        }
     }
+    const bool device_is_the_graph = failed.empty();
     // points the kernel could not serve take the CPU path
     if (!failed.empty()) {
         std::sort(failed.begin(), failed.end());
@@ -944,10 +1006,22 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         fprintf(stderr,
                 "\non-device build (device connect): %zu batches in %.2f s (insert kernel %.2f s, sort + connect + "
                 "remove %.2f s, graph read-back %.2f s); %zu requests, %zu removals, %u kept-last-edge, %zu points "
-                "took the CPU path\n",
-                n_batches, tot, t_ins, t_conn, t_sync, n_req, n_rem, counts[2], failed.size());
+                "ran again with a larger visited table, %zu took the CPU path\n",
+                n_batches, tot, t_ins, t_conn, t_sync, n_req, n_rem, counts[2], n_again, failed.size());
+        auto secs = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) {
+            return std::chrono::duration<double>(y - x).count();
+        };
+        fprintf(stderr,
+                "host phases: store_points %.2f s, levels + order + first %llu points on the CPU %.2f s, row clamp %.2f s, "
+                "upload %.2f s, buffers %.2f s, batch loop %.2f s\n",
+                secs(t_enter, t_stored), (unsigned long long)SEED, secs(t_stored, t_start), secs(t_start, t_clamped),
+                secs(t_clamped, t_uploaded), secs(t_uploaded, t_loop0), secs(t_loop0, t_sync0));
     }
     host.version++;
+    // the adjacency in HBM is the graph just read back: patch the few rows changed since and keep the snapshot
+    // (a build of tens of GB is otherwise followed by an upload of the same tens of GB)
+    if (device_is_the_graph && !(getenv("HNSW_MI355X_REUPLOAD") && atoi(getenv("HNSW_MI355X_REUPLOAD")) != 0))
+        (void)h->dev.refresh_rows(host, touched);
     return HNSW_OK;
 }
 

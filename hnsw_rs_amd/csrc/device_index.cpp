@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -106,6 +107,154 @@ static void parallel_rows(uint64_t n, F f) {
     for (auto &t : th) t.join();
 }
 
+// inline rows ("fat" layer-0 blocks, device_index.h): only small 8-bit indexes have them
+bool DeviceIndex::wants_inline_rows(const HostIndex &idx) const {
+    if (idx.kind != HNSW_VEC_QUANT8) return false;
+    int want = inline_rows;
+    if (const char *e = getenv("HNSW_MI355X_INLINE_ROWS")) want = atoi(e);
+    const uint32_t half = quant_half_bytes(idx.dim), S0 = adj_stride(idx.layer_m(0), 32);
+    const uint32_t used = 8 + 4 * (idx.dim / 8) + idx.dim % 8;
+    const bool room = S0 == 32 && half >= used + 4;
+    // d = 100 is served by the lean compact-layout kernel (search_lean.hip), faster at every launch size
+    // than the inline-rows loop: the 4-GB copy is only built there when asked for explicitly
+    if (want < 0 && idx.dim == 100 && !(getenv("HNSW_MI355X_LEAN_Q8") && atoi(getenv("HNSW_MI355X_LEAN_Q8")) == 0) &&
+        !(getenv("HNSW_MI355X_LEAN") && atoi(getenv("HNSW_MI355X_LEAN")) == 0))
+        want = 0;
+    const uint64_t need = (uint64_t)idx.len() * S0 * (2ull * half);
+    return room && (want == 1 || (want < 0 && need <= fat_budget_bytes));
+}
+
+// sorted ids into the row's S slots; true: the row has more than S ids, its last slot is left for the
+// overflow pointer
+static bool pack_adj_row(const std::vector<NodeID> &src, uint32_t *dst, uint32_t S, std::vector<NodeID> &tmp) {
+    tmp = src;
+    std::sort(tmp.begin(), tmp.end());
+    const size_t take = tmp.size() <= S ? tmp.size() : S - 1;
+    std::copy(tmp.begin(), tmp.begin() + take, dst);
+    std::fill(dst + take, dst + S, HX_EMPTY_SLOT);
+    return tmp.size() > S;
+}
+
+bool DeviceIndex::refresh_rows(const HostIndex &idx, const std::vector<uint64_t> &layer_row) {
+    if (!valid || replica || view.n_points != idx.len() || view.nb_layers != idx.nb_layers()) return false;
+    if (wants_inline_rows(idx) || view.fat_stride != 0) return false;
+    if (sizes_[4] != 4) return false;  // overflow lists already there: a fresh upload rebuilds them
+    if (hipSetDevice(device) != hipSuccess) return false;
+    // rows in the order upload() files overflow lists: layer 0 by id, then the upper rows by row index
+    std::vector<std::pair<uint64_t, uint32_t>> rows;  // (row index, 0 = adj0 / 1 = adj_up)
+    for (uint64_t key : layer_row) {
+        const uint32_t layer = (uint32_t)(key >> 32);
+        const NodeID id = (NodeID)key;
+        if (!idx.in_layer(layer, id)) return false;
+        rows.push_back(layer == 0 ? std::make_pair((uint64_t)id, 0u)
+                                  : std::make_pair((uint64_t)idx.upper_base[id] + layer - 1, 1u));
+    }
+    std::sort(rows.begin(), rows.end(), [](const auto &x, const auto &y) {
+        return x.second != y.second ? x.second < y.second : x.first < y.first;
+    });
+    rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+    std::vector<uint32_t> ovf_off(1, 0), ovf_nbrs, slots;
+    std::vector<NodeID> tmp;
+    for (const auto &r : rows) {
+        const bool up = r.second != 0;
+        const uint32_t S = up ? view.S1 : view.S0;
+        const std::vector<NodeID> &src = up ? idx.adj_up[r.first] : idx.adj0[r.first];
+        slots.assign(S, HX_EMPTY_SLOT);
+        if (pack_adj_row(src, slots.data(), S, tmp)) {
+            slots[S - 1] = HX_OVF_FLAG | (uint32_t)(ovf_off.size() - 1);
+            ovf_nbrs.insert(ovf_nbrs.end(), tmp.begin() + (S - 1), tmp.end());
+            ovf_off.push_back((uint32_t)ovf_nbrs.size());
+        }
+        uint32_t *dst = static_cast<uint32_t *>(bufs_[up ? 2 : 1]) + r.first * S;
+        if (hipMemcpy(dst, slots.data(), (size_t)S * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            valid = false;  // half-written: the next search uploads
+            return false;
+        }
+    }
+    if (!ovf_nbrs.empty()) {
+        void *off = nullptr, *nb = nullptr;
+        if (hipMalloc(&off, ovf_off.size() * 4) != hipSuccess || hipMalloc(&nb, ovf_nbrs.size() * 4) != hipSuccess ||
+            hipMemcpy(off, ovf_off.data(), ovf_off.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(nb, ovf_nbrs.data(), ovf_nbrs.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            if (off) (void)hipFree(off);
+            if (nb) (void)hipFree(nb);
+            valid = false;
+            return false;
+        }
+        (void)hipFree(bufs_[4]);
+        (void)hipFree(bufs_[5]);
+        bytes += ovf_off.size() * 4 + ovf_nbrs.size() * 4 - sizes_[4] - sizes_[5];
+        bufs_[4] = off;
+        bufs_[5] = nb;
+        sizes_[4] = ovf_off.size() * 4;
+        sizes_[5] = ovf_nbrs.size() * 4;
+        view.ovf_off = (const uint32_t *)off;
+        view.ovf_nbrs = (const uint32_t *)nb;
+    }
+    view.ep = idx.params.ep;
+    version_seen = idx.version;
+    return true;
+}
+
+// [lo, hi) on up to 16 threads
+template <class F>
+static void parallel_span(uint64_t lo, uint64_t hi, F f) {
+    const uint64_t n = hi - lo;
+    unsigned nt = std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+    if (n < 16384) nt = 1;
+    if (nt == 1) {
+        f(lo, hi);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(f, lo + n * t / nt, lo + n * (t + 1) / nt);
+    for (auto &t : th) t.join();
+}
+
+// Host rows -> device array in pieces through two pinned buffers: piece k + 1 is packed by the host threads
+// while piece k is on the wire.  (A pageable hipMemcpy of a row table of tens of GB runs at a fraction of the
+// link, and packing the whole table first doubles the host memory and adds a pass over it.)
+// fill(row_lo, row_hi, dst): writes rows [row_lo, row_hi) of `unit` bytes each.
+namespace {
+struct PinnedPair {
+    void *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    ~PinnedPair() {
+        for (int i = 0; i < 2; i++) {
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            if (buf[i]) (void)hipHostFree(buf[i]);
+        }
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+constexpr size_t PIECE_BYTES = 64ull << 20;
+}  // namespace
+
+template <class Fill>
+static int upload_pieces(PinnedPair &pp, void *dst, uint64_t n_rows, size_t unit, Fill fill) {
+    if (!pp.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&pp.stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipHostMalloc(&pp.buf[i], PIECE_BYTES, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&pp.ev[i], hipEventDisableTiming));
+        }
+    }
+    const uint64_t per = std::max<uint64_t>(1, PIECE_BYTES / unit);
+    int k = 0;
+    for (uint64_t lo = 0; lo < n_rows; lo += per, k ^= 1) {
+        const uint64_t hi = std::min(n_rows, lo + per);
+        HIP_TRY(hipEventSynchronize(pp.ev[k]));  // the copy that last read this buffer
+        fill(lo, hi, static_cast<unsigned char *>(pp.buf[k]));
+        HIP_TRY(hipMemcpyAsync(static_cast<unsigned char *>(dst) + lo * unit, pp.buf[k], (hi - lo) * unit,
+                               hipMemcpyHostToDevice, pp.stream));
+        HIP_TRY(hipEventRecord(pp.ev[k], pp.stream));
+    }
+    HIP_TRY(hipStreamSynchronize(pp.stream));
+    return HNSW_OK;
+}
+
 int DeviceIndex::upload(const HostIndex &idx, int dev) {
     const uint64_t N = idx.len();
     if (N == 0) {
@@ -130,129 +279,131 @@ int DeviceIndex::upload(const HostIndex &idx, int dev) {
     v.rem = idx.dim % 8;
     v.nb_layers = idx.nb_layers();
     v.ep = idx.params.ep;
-
-    // ---- vector rows ----
-    std::vector<uint8_t> rows;
-    if (idx.kind == HNSW_VEC_QUANT8) {
-        const uint32_t half = quant_half_bytes(idx.dim);
-        v.half_bytes = half;
-        v.row_stride = 2 * half;
-        rows.assign((size_t)N * v.row_stride, 0);
-        const uint32_t d = idx.dim, nch = d / 8, rem = d % 8;
-        parallel_rows(N, [&](uint64_t lo, uint64_t hi) {
-            for (uint64_t i = lo; i < hi; i++) {
-                const uint8_t *c = &idx.codes[i * d];
-                for (uint32_t h = 0; h < 2; h++) {
-                    uint8_t *o = &rows[i * v.row_stride + h * half];
-                    memcpy(o, &idx.mins[i], 4);
-                    memcpy(o + 4, &idx.deltas[i], 4);
-                    for (uint32_t ch = 0; ch < nch; ch++) memcpy(o + 8 + 4 * ch, c + 8 * ch + 4 * h, 4);
-                    if (h == 0) memcpy(o + 8 + 4 * nch, c + 8 * nch, rem);
-                }
-            }
-        });
-    } else {
-        v.half_bytes = 0;
-        v.row_stride = f32_row_stride(idx.dim);
-        rows.assign((size_t)N * v.row_stride, 0);
-        parallel_rows(N, [&](uint64_t lo, uint64_t hi) {
-            for (uint64_t i = lo; i < hi; i++)
-                memcpy(&rows[i * v.row_stride], &idx.vals[i * idx.dim], 4 * (size_t)idx.dim);
-        });
-    }
-
-    // ---- adjacency ----
+    const bool q8 = idx.kind == HNSW_VEC_QUANT8;
+    v.half_bytes = q8 ? quant_half_bytes(idx.dim) : 0;
+    v.row_stride = q8 ? 2 * v.half_bytes : f32_row_stride(idx.dim);
     v.S0 = adj_stride(idx.layer_m(0), 32);
     v.S1 = adj_stride(idx.params.m, 8);
-    std::vector<uint32_t> adj0((size_t)N * v.S0, HX_EMPTY_SLOT);
+
+    // ---- one vector row / one adjacency row in the device layout ----
+    auto pack_vector = [&](uint64_t i, uint8_t *o) {
+        if (q8) {
+            const uint32_t d = idx.dim, nch = d / 8, rem = d % 8, half = v.half_bytes;
+            const uint8_t *c = &idx.codes[i * d];
+            memset(o, 0, v.row_stride);
+            for (uint32_t h = 0; h < 2; h++) {
+                uint8_t *oh = o + h * half;
+                memcpy(oh, &idx.mins[i], 4);
+                memcpy(oh + 4, &idx.deltas[i], 4);
+                for (uint32_t ch = 0; ch < nch; ch++) memcpy(oh + 8 + 4 * ch, c + 8 * ch + 4 * h, 4);
+                if (h == 0) memcpy(oh + 8 + 4 * nch, c + 8 * nch, rem);
+            }
+        } else {
+            const size_t nb = 4 * (size_t)idx.dim;
+            memcpy(o, &idx.vals[i * idx.dim], nb);
+            if (nb < v.row_stride) memset(o + nb, 0, v.row_stride - nb);
+        }
+    };
+
+    // ---- inline rows: those (small) indexes also keep whole-table host copies to build the blocks from ----
+    const bool want_fat = wants_inline_rows(idx);
+
+    bytes = 0;
+    auto dev_alloc = [&](int i, size_t nbytes) -> int {
+        HIP_TRY(hipMalloc(&bufs_[i], nbytes));
+        sizes_[i] = nbytes;
+        bytes += nbytes;
+        return HNSW_OK;
+    };
+    int rc;
+    std::vector<uint64_t> over0;  // layer-0 rows with more than S0 ids (rare)
+    std::vector<uint8_t> rows_h;  // whole-table host copies: only when the inline rows are built from them
+    std::vector<uint32_t> adj0_h;
+    if ((rc = dev_alloc(0, (size_t)N * v.row_stride)) != HNSW_OK) return rc;
+    if ((rc = dev_alloc(1, (size_t)N * v.S0 * 4)) != HNSW_OK) return rc;
+    {
+        PinnedPair pp;
+        if (want_fat) rows_h.resize((size_t)N * v.row_stride);
+        rc = upload_pieces(pp, bufs_[0], N, v.row_stride, [&](uint64_t lo, uint64_t hi, unsigned char *dst) {
+            parallel_span(lo, hi, [&](uint64_t a, uint64_t b) {
+                for (uint64_t i = a; i < b; i++) pack_vector(i, dst + (i - lo) * v.row_stride);
+            });
+            if (want_fat) memcpy(&rows_h[lo * v.row_stride], dst, (hi - lo) * v.row_stride);
+        });
+        if (rc != HNSW_OK) return rc;
+        if (want_fat) adj0_h.resize((size_t)N * v.S0);
+        std::mutex over_mu;
+        rc = upload_pieces(pp, bufs_[1], N, (size_t)v.S0 * 4, [&](uint64_t lo, uint64_t hi, unsigned char *dst) {
+            parallel_span(lo, hi, [&](uint64_t a, uint64_t b) {
+                std::vector<NodeID> tmp;
+                std::vector<uint64_t> mine;
+                for (uint64_t i = a; i < b; i++)
+                    if (pack_adj_row(idx.adj0[i], reinterpret_cast<uint32_t *>(dst) + (i - lo) * v.S0, v.S0, tmp)) mine.push_back(i);
+                if (!mine.empty()) {
+                    std::lock_guard<std::mutex> g(over_mu);
+                    over0.insert(over0.end(), mine.begin(), mine.end());
+                }
+            });
+            if (want_fat) memcpy(&adj0_h[lo * v.S0], dst, (hi - lo) * (size_t)v.S0 * 4);
+        });
+        if (rc != HNSW_OK) return rc;
+    }
+    std::sort(over0.begin(), over0.end());
+
+    // ---- upper layers, overflow lists (small) ----
     std::vector<uint32_t> adj_up(std::max<size_t>(1, idx.adj_up.size()) * v.S1, HX_EMPTY_SLOT);
     std::vector<uint32_t> ovf_off(1, 0), ovf_nbrs;
-    auto pack_row = [&](const std::vector<NodeID> &src, uint32_t *dst, uint32_t S,
-                        std::vector<NodeID> &tmp) -> bool {
-        tmp = src;
-        std::sort(tmp.begin(), tmp.end());
-        if (tmp.size() <= S) {
-            std::copy(tmp.begin(), tmp.end(), dst);
-            return false;
-        }
-        std::copy(tmp.begin(), tmp.begin() + (S - 1), dst);
-        return true;  // the caller appends the overflow (serially)
-    };
-    // rows that fit are packed in parallel; the rare overflow rows are fixed up serially
-    std::vector<uint64_t> over0;
-    {
-        std::vector<std::vector<uint64_t>> over_t(64);
-        std::atomic<unsigned> slot{0};
-        parallel_rows(N, [&](uint64_t lo, uint64_t hi) {
-            const unsigned me = slot.fetch_add(1);
-            std::vector<NodeID> tmp;
-            for (uint64_t i = lo; i < hi; i++)
-                if (pack_row(idx.adj0[i], &adj0[i * v.S0], v.S0, tmp)) over_t[me].push_back(i);
-        });
-        for (auto &o : over_t) over0.insert(over0.end(), o.begin(), o.end());
-        std::sort(over0.begin(), over0.end());
-    }
-    auto add_overflow = [&](const std::vector<NodeID> &src, uint32_t *dst, uint32_t S) {
+    auto overflow_slot = [&](const std::vector<NodeID> &src, uint32_t S) -> uint32_t {
         std::vector<NodeID> tmp = src;
         std::sort(tmp.begin(), tmp.end());
-        dst[S - 1] = HX_OVF_FLAG | (uint32_t)(ovf_off.size() - 1);
+        const uint32_t slot = HX_OVF_FLAG | (uint32_t)(ovf_off.size() - 1);
         ovf_nbrs.insert(ovf_nbrs.end(), tmp.begin() + (S - 1), tmp.end());
         ovf_off.push_back((uint32_t)ovf_nbrs.size());
+        return slot;
     };
-    for (uint64_t i : over0) add_overflow(idx.adj0[i], &adj0[i * v.S0], v.S0);
+    for (uint64_t i : over0) {
+        const uint32_t slot = overflow_slot(idx.adj0[i], v.S0);
+        HIP_TRY(hipMemcpy(static_cast<uint32_t *>(bufs_[1]) + i * v.S0 + (v.S0 - 1), &slot, 4, hipMemcpyHostToDevice));
+        if (want_fat) adj0_h[i * v.S0 + (v.S0 - 1)] = slot;
+    }
     {
         std::vector<NodeID> tmp;
         for (size_t r = 0; r < idx.adj_up.size(); r++)
-            if (pack_row(idx.adj_up[r], &adj_up[r * v.S1], v.S1, tmp))
-                add_overflow(idx.adj_up[r], &adj_up[r * v.S1], v.S1);
+            if (pack_adj_row(idx.adj_up[r], &adj_up[r * v.S1], v.S1, tmp))
+                adj_up[r * v.S1 + (v.S1 - 1)] = overflow_slot(idx.adj_up[r], v.S1);
     }
     if (ovf_nbrs.empty()) ovf_nbrs.push_back(HX_EMPTY_SLOT);
     std::vector<uint32_t> ub(idx.upper_base.begin(), idx.upper_base.end());
     ub.resize(N, UINT32_MAX);
 
-    // ---- inline rows ("fat" layer-0 blocks), see device_index.h ----
     std::vector<uint8_t> fat;
-    {
-        int want = inline_rows;
-        if (const char *e = getenv("HNSW_MI355X_INLINE_ROWS")) want = atoi(e);
-        const uint32_t used = 8 + v.nch4 + v.rem;
-        const bool room = idx.kind == HNSW_VEC_QUANT8 && v.S0 == 32 && v.half_bytes >= used + 4;
-        // d = 100 is served by the lean compact-layout kernel (search_lean.hip), faster at every launch size
-        // than the inline-rows loop: the 4-GB copy is only built there when asked for explicitly
-        if (want < 0 && idx.dim == 100 && !(getenv("HNSW_MI355X_LEAN_Q8") && atoi(getenv("HNSW_MI355X_LEAN_Q8")) == 0) &&
-            !(getenv("HNSW_MI355X_LEAN") && atoi(getenv("HNSW_MI355X_LEAN")) == 0))
-            want = 0;
-        const uint64_t need = (uint64_t)N * v.S0 * v.row_stride;
-        if (room && (want == 1 || (want < 0 && need <= fat_budget_bytes))) {
-            v.fat_stride = (uint64_t)v.S0 * v.row_stride;
-            fat.assign(need, 0);
-            const uint32_t idpos = v.half_bytes - 4;
-            parallel_rows(N, [&](uint64_t lo, uint64_t hi) {
-                for (uint64_t i = lo; i < hi; i++) {
-                    for (uint32_t k = 0; k < v.S0; k++) {
-                        const uint32_t nb = adj0[i * v.S0 + k];
-                        uint8_t *o = &fat[i * v.fat_stride + (uint64_t)k * v.row_stride];
-                        if (nb != HX_EMPTY_SLOT && !(nb & HX_OVF_FLAG))
-                            memcpy(o, &rows[(size_t)nb * v.row_stride], v.row_stride);
-                        memcpy(o + idpos, &nb, 4);
-                    }
+    if (want_fat) {
+        v.fat_stride = (uint64_t)v.S0 * v.row_stride;
+        fat.assign((uint64_t)N * v.fat_stride, 0);
+        const uint32_t idpos = v.half_bytes - 4;
+        parallel_rows(N, [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t i = lo; i < hi; i++) {
+                for (uint32_t k = 0; k < v.S0; k++) {
+                    const uint32_t nb = adj0_h[i * v.S0 + k];
+                    uint8_t *o = &fat[i * v.fat_stride + (uint64_t)k * v.row_stride];
+                    if (nb != HX_EMPTY_SLOT && !(nb & HX_OVF_FLAG)) memcpy(o, &rows_h[(size_t)nb * v.row_stride], v.row_stride);
+                    memcpy(o + idpos, &nb, 4);
                 }
-            });
-        }
+            }
+        });
     }
 
     struct Up {
         const void *src;
         size_t nbytes;
-    } ups[7] = {{rows.data(), rows.size()},
-                {adj0.data(), adj0.size() * 4},
+    } ups[7] = {{nullptr, 0},
+                {nullptr, 0},
                 {adj_up.data(), adj_up.size() * 4},
                 {ub.data(), ub.size() * 4},
                 {ovf_off.data(), ovf_off.size() * 4},
                 {ovf_nbrs.data(), ovf_nbrs.size() * 4},
                 {fat.data(), fat.size()}};
-    bytes = 0;
-    for (int i = 0; i < 7; i++) {
+    for (int i = 2; i < 7; i++) {
         if (ups[i].nbytes == 0) continue;
         if (i == 6) {  // the inline-rows copy is optional: without room for it the compact path serves
             if (hipMalloc(&bufs_[i], ups[i].nbytes) != hipSuccess) {

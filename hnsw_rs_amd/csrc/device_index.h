@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <vector>
 
 #include "host_index.h"
 
@@ -135,6 +136,13 @@ class DeviceIndex {
     uint64_t fat_budget_bytes = 64ull << 30;
     void release();
     bool current(const HostIndex &idx) const { return valid && (replica || version_seen == idx.version); }
+    // After an on-device build the adjacency in HBM IS the graph the host just read back, except for the few
+    // rows the host touched afterwards (kept-last-edge records): those rows are re-packed and copied, and the
+    // snapshot is declared current for idx.version -- instead of uploading tens of GB again.  Returns false
+    // (snapshot left as it was, the next search uploads) when that is not possible: inline rows wanted, or
+    // overflow lists already present.  layer_row: (layer << 32) | node id.
+    bool refresh_rows(const HostIndex &idx, const std::vector<uint64_t> &layer_row);
+    bool wants_inline_rows(const HostIndex &idx) const;
 
     // mutable views of the adjacency arrays (the on-device build scatters dirty rows into them)
     uint32_t *adj0_mut() { return static_cast<uint32_t *>(bufs_[1]); }
@@ -175,7 +183,8 @@ uint32_t default_slots_log2(uint32_t ef);
 uint32_t default_slots_log2(uint32_t ef, uint32_t s0);
 uint32_t max_slots_log2(uint32_t ef);
 
-int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipStream_t stream);
+int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipStream_t stream, int table_adjust = 0);
+int insert_table_first_adjust(const DevView &v, const InsertArgs &a);
 int launch_connect(const DevView &v, const ConnectArgs &a, hipStream_t stream);
 int launch_remove(const DevView &v, const ConnectArgs &a, hipStream_t stream);
 int launch_scatter_rows(uint32_t *dst, uint32_t S, const uint32_t *d_row_index, const uint32_t *d_data,

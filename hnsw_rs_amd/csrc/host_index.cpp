@@ -11,6 +11,8 @@
 
 #include "host_index.h"
 
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -141,6 +143,57 @@ float HostIndex::dist2other(const PointView &a, const PointView &b) const {
                : dist_full(dim, a.vals, b.vals);
 }
 
+// VecBase::dist2many (vectors/src/lib.rs:17-22): a's distance to each of n stored points.  Every distance is
+// its own left-to-right chain exactly as in dist_full (full.rs:23-29); for f32 rows eight of them are
+// interleaved, so that the dependent adds of one chain do not wait for each other (a 256-d distance is 256
+// serial adds: the sequential inserts of a build spend their time there).
+template <int K>
+static inline void dist_full_chains(uint32_t dim, const float *x, const float *const *r, float *out) {
+    float acc[K];
+    for (int k = 0; k < K; k++) acc[k] = 0.0f;
+    for (uint32_t e = 0; e < dim; e++) {
+        const float xe = x[e];
+        for (int k = 0; k < K; k++) {
+            const float t = xe - r[k][e];
+            acc[k] += t * t;
+        }
+    }
+    for (int k = 0; k < K; k++) out[k] = std::sqrt(acc[k]);
+}
+void HostIndex::dist2many(const PointView &a, const NodeID *ids, size_t n, float *out) const {
+    if (kind != HNSW_VEC_F32) {
+        for (size_t i = 0; i < n; i++) {
+            PointView b;
+            get_point(ids[i], &b);
+            out[i] = dist2other(a, b);
+        }
+        return;
+    }
+    const float *r[8];
+    size_t i = 0;
+    auto rows_at = [&](size_t cnt) {
+        for (size_t k = 0; k < cnt; k++) r[k] = &vals[(size_t)ids[i + k] * dim];
+    };
+    for (; i + 8 <= n; i += 8) {
+        rows_at(8);
+        dist_full_chains<8>(dim, a.vals, r, out + i);
+    }
+    if (i + 4 <= n) {
+        rows_at(4);
+        dist_full_chains<4>(dim, a.vals, r, out + i);
+        i += 4;
+    }
+    if (i + 2 <= n) {
+        rows_at(2);
+        dist_full_chains<2>(dim, a.vals, r, out + i);
+        i += 2;
+    }
+    if (i < n) {
+        rows_at(1);
+        dist_full_chains<1>(dim, a.vals, r, out + i);
+    }
+}
+
 void HostIndex::ensure_locks() {
     if (lock0_n_ != adj0.size()) {
         lock0_n_ = adj0.size();
@@ -181,19 +234,6 @@ void HostIndex::unlock_row(uint32_t layer, NodeID id) const {
         if (!lock_up_ || r >= lock_up_n_) return;
         lock_up_[r].store(0, std::memory_order_release);
     }
-}
-
-// Layers::add_node + add_level, graph/src/layers.rs:48-70
-void HostIndex::add_node_rows(NodeID id, uint32_t level) {
-    while (layer_nodes.size() <= level) layer_nodes.emplace_back();
-    if (adj0.size() <= id) adj0.resize((size_t)id + 1);
-    if (upper_base.size() <= id) upper_base.resize((size_t)id + 1, UINT32_MAX);
-    adj0[id].reserve(layer_m(0) + 2);
-    if (level >= 1 && upper_base[id] == UINT32_MAX) {
-        upper_base[id] = (uint32_t)adj_up.size();
-        adj_up.resize(adj_up.size() + level);
-    }
-    for (uint32_t l = 0; l <= level; l++) layer_nodes[l].push_back(id);  // ids arrive ascending
 }
 
 bool HostIndex::neighbors_vec(uint32_t layer, NodeID id, std::vector<NodeID> *out) const {
@@ -346,7 +386,8 @@ class Inserter {
     std::map<size_t, LayerRes> insertion_results;                     // one point per layer
     std::map<size_t, std::map<NodeID, std::vector<Dist>>> prune_results;
     // scratch
-    std::vector<NodeID> nb;
+    std::vector<NodeID> nb, fresh;
+    std::vector<float> dists;
     std::vector<Dist> batch, tmp;
 
     static bool set_insert(std::vector<Dist> &v, size_t head, const Dist &d) {
@@ -394,19 +435,23 @@ class Inserter {
                 return HNSW_ERR_NODE_NOT_IN_GRAPH;
             }
             batch.clear();
+            fresh.clear();
             for (NodeID n : nb) {
                 if (!visit(n)) continue;
-                PointView p;
-                if (!idx.get_point(n, &p)) {
+                if (n >= idx.len()) {
                     set_error("Could get point %u", n);
                     return HNSW_ERR_ARG;
                 }
-                const float d = idx.dist2other(p, point);
-                if (std::isnan(d)) {
-                    set_error("NaN distance to point %u", n);
+                fresh.push_back(n);
+            }
+            dists.resize(fresh.size());
+            idx.dist2many(point, fresh.data(), fresh.size(), dists.data());
+            for (size_t k = 0; k < fresh.size(); k++) {
+                if (std::isnan(dists[k])) {
+                    set_error("NaN distance to point %u", fresh[k]);
                     return HNSW_ERR_NAN_INPUT;
                 }
-                batch.push_back(Dist{n, d});
+                batch.push_back(Dist{fresh[k], dists[k]});
             }
             for (const Dist &e : batch) {
                 const Dist f2 = selected.back();
@@ -442,12 +487,13 @@ class Inserter {
                 set_error("Node %u is not in the Graph", node.id);
                 return HNSW_ERR_NODE_NOT_IN_GRAPH;
             }
-            for (NodeID n : nb) {
-                PointView np;
-                if (!idx.get_point(n, &np)) return HNSW_ERR_ARG;
-                const float d = idx.dist2other(point, np);  // points.distance(point.id, neighbor)
-                if (std::isnan(d)) return HNSW_ERR_NAN_INPUT;
-                tmp.push_back(Dist{n, d});
+            for (NodeID n : nb)
+                if (n >= idx.len()) return HNSW_ERR_ARG;
+            dists.resize(nb.size());
+            idx.dist2many(point, nb.data(), nb.size(), dists.data());  // points.distance(point.id, neighbor)
+            for (size_t k = 0; k < nb.size(); k++) {
+                if (std::isnan(dists[k])) return HNSW_ERR_NAN_INPUT;
+                tmp.push_back(Dist{nb[k], dists[k]});
             }
         }
         cand.insert(cand.end(), tmp.begin(), tmp.end());
@@ -459,19 +505,23 @@ class Inserter {
             const Dist e = cand[cand_head++];
             PointView ep;
             if (!idx.get_point(e.id, &ep)) return HNSW_ERR_ARG;
-            // get_nearest_from_selected, results.rs:69-77
-            Dist nearest{0, 0.0f};
-            bool first = true;
-            for (const Dist &s : selected) {
-                PointView sp;
-                idx.get_point(s.id, &sp);
-                const Dist d{s.id, idx.dist2other(ep, sp)};
-                if (first || dist_lt(d, nearest)) {
-                    nearest = d;
-                    first = false;
-                }
+            // get_nearest_from_selected, results.rs:69-77, and `e < nearest` (searcher.rs:128-139): e is kept
+            // iff it is below Dist(s, d(e, s)) for EVERY selected s, so the scan stops at the first s that is
+            // not above it (most candidates are dropped by one of the nearest few); four distances at a time
+            bool keep = true;
+            fresh.clear();
+            for (const Dist &s : selected) fresh.push_back(s.id);
+            for (size_t k0 = 0; k0 < fresh.size() && keep; k0 += 4) {
+                const size_t cnt = std::min<size_t>(4, fresh.size() - k0);
+                float d4[4];
+                idx.dist2many(ep, fresh.data() + k0, cnt, d4);
+                for (size_t k = 0; k < cnt; k++)
+                    if (!dist_lt(e, Dist{fresh[k0 + k], d4[k]})) {
+                        keep = false;
+                        break;
+                    }
             }
-            if (dist_lt(e, nearest)) {
+            if (keep) {
                 set_insert(selected, 0, e);
             } else {
                 set_insert(visited_h, 0, e);
@@ -546,11 +596,11 @@ int HostIndex::apply_insertion_results(Inserter &ins) {
             get_point(x.id, &a);
             std::vector<Dist> ds;
             ds.reserve(ins.nb.size());
-            for (NodeID n : ins.nb) {
-                PointView b;
-                if (!get_point(n, &b)) return HNSW_ERR_ARG;
-                ds.push_back(Dist{n, dist2other(a, b)});
-            }
+            for (NodeID n : ins.nb)
+                if (n >= len()) return HNSW_ERR_ARG;
+            ins.dists.resize(ins.nb.size());
+            dist2many(a, ins.nb.data(), ins.nb.size(), ins.dists.data());
+            for (size_t k = 0; k < ins.nb.size(); k++) ds.push_back(Dist{ins.nb[k], ins.dists[k]});
             std::sort(ds.begin(), ds.end(), dist_lt);  // select_simple, template.rs:614-621
             if (ds.size() > lm) ds.resize(lm);
             ins.prune_results[l][x.id] = std::move(ds);
@@ -613,6 +663,14 @@ int HostIndex::connect_point(NodeID point_id, const std::vector<std::vector<Dist
 }
 
 // HNSW::store_points, template.rs:269-293
+// Fresh storage for a bulk insert is first touched by the copying threads: with 2-MiB pages (where the kernel
+// grants them on madvise) that is one fault per 2 MiB instead of one per 4 KiB.  Advice only.
+static void advise_huge_pages(void *p, size_t nbytes) {
+    const uintptr_t H = (uintptr_t)2 << 20;
+    const uintptr_t a = ((uintptr_t)p + H - 1) & ~(H - 1), e = ((uintptr_t)p + nbytes) & ~(H - 1);
+    if (e > a) (void)madvise(reinterpret_cast<void *>(a), e - a, MADV_HUGEPAGE);
+}
+
 int HostIndex::store_points(const float *rows, uint64_t n, const uint8_t *levels_in,
                             std::vector<NodeID> *ids_out, uint32_t nb_threads) {
     if (n == 0) {
@@ -629,28 +687,17 @@ int HostIndex::store_points(const float *rows, uint64_t n, const uint8_t *levels
         draw_levels(n, drawn.data());
         levels_in = drawn.data();
     }
-    // validate / quantise everything first so that a bad row leaves the index untouched
-    std::vector<uint8_t> new_codes;
-    std::vector<float> new_mins, new_deltas;
-    if (kind == HNSW_VEC_QUANT8) {
-        new_codes.resize((size_t)n * dim);
-        new_mins.resize(n);
-        new_deltas.resize(n);
-        // rows are independent: quantise on nb_threads threads, report the first bad row
-        std::atomic<uint64_t> bad{UINT64_MAX};
-        auto work = [&](uint64_t lo, uint64_t hi) {
-            for (uint64_t i = lo; i < hi && bad.load(std::memory_order_relaxed) == UINT64_MAX; i++) {
-                int rc = quantize(rows + i * dim, dim, &new_mins[i], &new_deltas[i],
-                                  &new_codes[(size_t)i * dim]);
-                if (rc == HNSW_OK && !std::isfinite(new_deltas[i])) rc = HNSW_ERR_NAN_INPUT;
-                if (rc != HNSW_OK) {
-                    uint64_t cur = bad.load();
-                    while (i < cur && !bad.compare_exchange_weak(cur, i)) {
-                    }
-                    return;
-                }
-            }
-        };
+    // rows are independent: quantise / copy them on nb_threads threads straight into the stored arrays (each
+    // thread first-touches its own part), report the first bad row and put the arrays back as they were
+    const NodeID first = (NodeID)len();
+    const size_t old_codes = codes.size(), old_vals = vals.size(), old_n = mins.size();
+    std::atomic<uint64_t> bad{UINT64_MAX};
+    auto mark_bad = [&](uint64_t i) {
+        uint64_t cur = bad.load();
+        while (i < cur && !bad.compare_exchange_weak(cur, i)) {
+        }
+    };
+    auto run = [&](auto &&work) {
         const unsigned nt = (unsigned)std::min<uint64_t>(std::max(1u, nb_threads), std::max<uint64_t>(1, n / 4096));
         if (nt <= 1) {
             work(0, n);
@@ -659,28 +706,79 @@ int HostIndex::store_points(const float *rows, uint64_t n, const uint8_t *levels
             for (unsigned t = 0; t < nt; t++) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
             for (auto &t : th) t.join();
         }
-        if (bad.load() != UINT64_MAX) {
-            set_error("row %llu: NaN / non-finite range cannot be quantised", (unsigned long long)bad.load());
-            return HNSW_ERR_NAN_INPUT;
-        }
-    } else {
-        for (uint64_t i = 0; i < n * dim; i++)
-            if (std::isnan(rows[i])) {
-                set_error("row %llu contains NaN", (unsigned long long)(i / dim));
-                return HNSW_ERR_NAN_INPUT;
-            }
-    }
-    const NodeID first = (NodeID)len();
+    };
     if (kind == HNSW_VEC_QUANT8) {
-        codes.insert(codes.end(), new_codes.begin(), new_codes.end());
-        mins.insert(mins.end(), new_mins.begin(), new_mins.end());
-        deltas.insert(deltas.end(), new_deltas.begin(), new_deltas.end());
+        codes.resize(old_codes + (size_t)n * dim);
+        advise_huge_pages(codes.data() + old_codes, (size_t)n * dim);
+        mins.resize(old_n + n);
+        deltas.resize(old_n + n);
+        run([&](uint64_t lo, uint64_t hi) {
+            for (uint64_t i = lo; i < hi && bad.load(std::memory_order_relaxed) == UINT64_MAX; i++) {
+                int rc = quantize(rows + i * dim, dim, &mins[old_n + i], &deltas[old_n + i],
+                                  &codes[old_codes + (size_t)i * dim]);
+                if (rc == HNSW_OK && !std::isfinite(deltas[old_n + i])) rc = HNSW_ERR_NAN_INPUT;
+                if (rc != HNSW_OK) {
+                    mark_bad(i);
+                    return;
+                }
+            }
+        });
     } else {
-        vals.insert(vals.end(), rows, rows + n * dim);
+        vals.resize(old_vals + (size_t)n * dim);
+        advise_huge_pages(vals.data() + old_vals, (size_t)n * dim * sizeof(float));
+        run([&](uint64_t lo, uint64_t hi) {
+            // blocks of rows small enough to stay in cache between the NaN scan and the copy
+            const uint64_t step = std::max<uint64_t>(1, 16384 / dim);
+            for (uint64_t i = lo; i < hi; i += step) {
+                const uint64_t e = std::min(hi, i + step);
+                const float *src = rows + i * dim;
+                const size_t cnt = (size_t)(e - i) * dim;
+                bool nan = false;
+                for (size_t k = 0; k < cnt; k++) nan |= src[k] != src[k];
+                if (nan) {
+                    for (size_t k = 0; k < cnt; k++)
+                        if (src[k] != src[k]) {
+                            mark_bad(i + k / dim);
+                            break;
+                        }
+                    return;
+                }
+                memcpy(&vals[old_vals + (size_t)i * dim], src, cnt * sizeof(float));
+            }
+        });
+    }
+    if (bad.load() != UINT64_MAX) {
+        codes.resize(old_codes);
+        mins.resize(old_n);
+        deltas.resize(old_n);
+        vals.resize(old_vals);
+        if (kind == HNSW_VEC_QUANT8) {
+            set_error("row %llu: NaN / non-finite range cannot be quantised", (unsigned long long)bad.load());
+        } else {
+            set_error("row %llu contains NaN", (unsigned long long)bad.load());
+        }
+        return HNSW_ERR_NAN_INPUT;
     }
     levels.insert(levels.end(), levels_in, levels_in + n);
-    adj0.reserve(len());
-    for (uint64_t i = 0; i < n; i++) add_node_rows(first + (NodeID)i, levels[first + i]);
+    // graph rows of the new nodes (Layers::add_node + add_level, graph/src/layers.rs:48-70): the per-node bookkeeping is serial (ids arrive ascending), the allocation
+    // of the layer-0 rows -- one small block per node -- runs on the threads
+    const size_t total = len();
+    adj0.resize(total);
+    upper_base.resize(total, UINT32_MAX);
+    for (uint64_t i = 0; i < n; i++) {
+        const NodeID id = first + (NodeID)i;
+        const uint32_t level = levels[id];
+        while (layer_nodes.size() <= level) layer_nodes.emplace_back();
+        if (level >= 1 && upper_base[id] == UINT32_MAX) {
+            upper_base[id] = (uint32_t)adj_up.size();
+            adj_up.resize(adj_up.size() + level);
+        }
+        for (uint32_t l = 0; l <= level; l++) layer_nodes[l].push_back(id);
+    }
+    run([&](uint64_t lo, uint64_t hi) {
+        const size_t cap = layer_m(0) + 2;
+        for (uint64_t i = lo; i < hi; i++) adj0[first + i].reserve(cap);
+    });
     // template.rs:283-290: ep = first key of the top layer (hash order there; smallest id here)
     params.ep = layer_nodes.back().front();
     if (ids_out) {

@@ -55,6 +55,26 @@ struct PointView {
 
 class Inserter;
 
+// std::vector storage that is NOT zero-filled by resize(): the stored rows of a bulk insert are first touched
+// by the threads that copy them in (a 51-GB row table is otherwise one thread's memset before the copy)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = NoInitAlloc<U>;
+    };
+    NoInitAlloc() = default;
+    template <class U>
+    NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <class U, class... A>
+    void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0)
+            ::new ((void *)p) U;
+        else
+            ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+
 class HostIndex {
   public:
     HostIndex(uint32_t m, uint32_t ef_cons, uint32_t dim, int vec_kind);
@@ -63,13 +83,14 @@ class HostIndex {
     // ---- points (points/src/points.rs SimplePoints, stored SoA) ----
     int kind;
     uint32_t dim;
-    std::vector<uint8_t> codes;     // QUANT8: N x dim
-    std::vector<float> mins, deltas;  // QUANT8: N
-    std::vector<float> vals;        // F32: N x dim
+    std::vector<uint8_t, NoInitAlloc<uint8_t>> codes;  // QUANT8: N x dim
+    std::vector<float> mins, deltas;                   // QUANT8: N
+    std::vector<float, NoInitAlloc<float>> vals;       // F32: N x dim
     std::vector<uint8_t> levels;    // N
     uint64_t len() const { return levels.size(); }
     bool get_point(NodeID id, PointView *p) const;
     float dist2other(const PointView &a, const PointView &b) const;
+    void dist2many(const PointView &a, const NodeID *ids, size_t n, float *out) const;
 
     // ---- layered graph (graph/src/layers.rs, graph/src/graph.rs) ----
     // A node of level L belongs to layers 0..L (layers.rs:63-70).  Layer 0 rows are indexed by
@@ -125,7 +146,6 @@ class HostIndex {
     void draw_levels(uint64_t n, uint8_t *out) const;
 
   private:
-    void add_node_rows(NodeID id, uint32_t level);
     void lock_row(uint32_t layer, NodeID id) const;
     void unlock_row(uint32_t layer, NodeID id) const;
     void ensure_locks();

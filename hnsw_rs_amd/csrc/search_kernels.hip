@@ -2298,7 +2298,16 @@ hx_scatter_rows_kernel(uint32_t *dst, uint32_t S, const uint32_t *row_index, con
     for (uint32_t k = threadIdx.x; k < S; k += 64) out[k] = data[(size_t)i * S + k];
 }
 
-int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipStream_t stream) {
+// First-attempt size of the insert kernel's visited table, relative to the standard one: - 1 (2048 slots, 8 KiB)
+// for ef_construction <= 32 on 32-slot rows.  LDS is what limits the insert kernel's waves per CU (6 with the
+// standard 16-KiB table at d = 256, 10 with 8 KiB): 16M x 256d, insert kernel 12.3 -> 10.1 s with 29 points of
+// 16M filling the small table (they run again with adjust + 1; round 3).
+int insert_table_first_adjust(const DevView &v, const InsertArgs &a) {
+    if (const char *e = getenv("HNSW_MI355X_INSERT_TABLE_ADJUST")) return atoi(e);  // A/B runs
+    return (a.ef_cons <= 32 && v.S0 <= 32) ? -1 : 0;
+}
+
+int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipStream_t stream, int table_adjust) {
     if (nblocks == 0) return HNSW_OK;
     if (a.m > 128 || a.m == 0 || a.ef_cons > 64 * HX_MAX_R) {
         set_error("on-device build supports m <= 128 and ef_construction <= 512");
@@ -2309,6 +2318,9 @@ int launch_insert(const DevView &v, const InsertArgs &a, uint32_t nblocks, hipSt
     // point that still fills it takes the CPU path after the build, like every point whose search fails)
     uint32_t slots_log2 = 12 + (a.ef_cons > 64 ? 1 : 0) + (a.ef_cons > 160 ? 1 : 0);
     if (v.S0 > 64) slots_log2 = std::max(slots_log2, std::min(15u, default_slots_log2(a.ef_cons, v.S0)));
+    // table_adjust: the device-connect build first runs a batch with HALF the table where that buys waves per
+    // CU (insert_table_first_adjust) and runs the few points that fill it again with a larger one
+    slots_log2 = (uint32_t)std::min(15, std::max(9, (int)slots_log2 + table_adjust));
     const size_t yq_bytes =
         ((v.kind == HNSW_VEC_QUANT8 ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4) + 15) & ~15ull;
     const size_t lds = (4ull << slots_log2) + 64ull * HX_MAX_R * 8 + 128 * 8 + 2 * yq_bytes + 256 /* rank -> id words */;

@@ -5,7 +5,7 @@ import numpy as np
 import hnsw_rs_amd as H
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 kind = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-d, m = 100, 16
+d, m = int(os.environ.get('DIM', '100')), 16
 recipe = int(os.environ.get('RECIPE', '0'))
 thr = min(32, os.cpu_count())
 vs = H.synth_rows(recipe, 0x5EED0001, 0, N, d, thr); qs = H.synth_rows(recipe, 0x5EED0002, 0, 1024, d, 8)

@@ -250,7 +250,9 @@ def test_full_size_properties_1m_x_100d(kind):
     (distance, id) and holds n distinct ids; (2) every reported distance is bit-for-bit the distance kernel's for that
     (query, id) -- VecBase::dist2many, vectors/src/lib.rs:17-22; (3) the same batch twice gives the same bits;
     (4) a query answers the same alone as inside a batch of 1024 (one wave, one LDS block per query); (5) the exact
-    nearest neighbour (exhaustive scan, template.rs:531-541) is in the top 10 for >= 98 % of the queries."""
+    nearest neighbour (exhaustive scan, template.rs:531-541) is in the top 10 for >= 98 % of the queries; (6) the
+    snapshot the on-device build leaves in HBM (adjacency as built, the kept-last-edge rows patched with their
+    overflow lists) answers bit for bit like a fresh upload of the host graph."""
     n_pts, d, m, n = 1_000_000, 100, 16, 10
     vs = H.synth_rows(0, 0x5EED0001, 0, n_pts, d, 16)
     qs = H.synth_rows(0, 0x5EED0002, 0, 1024, d, 8)
@@ -276,6 +278,11 @@ def test_full_size_properties_1m_x_100d(kind):
     got, _, _, _ = idx.search_batch(qs[:128], n, 68)
     hit = sum(int(truth[i, 0] in got[i]) for i in range(128))
     assert hit >= 126, hit
+    kept = idx.search_batch(qs, n, 68)
+    idx.set_option("inline_budget_mb", 65536)  # any layout option drops the snapshot: the next search uploads
+    fresh = idx.search_batch(qs, n, 68)
+    assert np.array_equal(kept[0], fresh[0]) and np.array_equal(kept[1].view(np.uint32), fresh[1].view(np.uint32))
+    assert np.array_equal(np.asarray(kept[3]), np.asarray(fresh[3]))
 
 
 @pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
