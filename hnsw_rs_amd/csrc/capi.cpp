@@ -622,7 +622,8 @@ struct ShardCtx {
     hnsw_allgather_fn allgather;
     void *ctx;
 };
-constexpr uint32_t SH_HEADER = 64, SH_FAILCAP = 1024, SH_BCAP = 8192;
+// SH_BCAP: the largest batch (option gpu_build_batch_max, default 8192); buffers and exchange slots are sized for it
+constexpr uint32_t SH_HEADER = 64, SH_FAILCAP = 1024, SH_BCAP = 32768;
 inline uint32_t shard_slot_records(uint32_t m, uint32_t world) {
     return ((SH_BCAP + world - 1) / world) * m * 4;  // both directions, 2 x slack for upper layers
 }

@@ -713,7 +713,7 @@ int HostIndex::store_points(const float *rows, uint64_t n, const uint8_t *levels
         mins.resize(old_n + n);
         deltas.resize(old_n + n);
         run([&](uint64_t lo, uint64_t hi) {
-            for (uint64_t i = lo; i < hi && bad.load(std::memory_order_relaxed) == UINT64_MAX; i++) {
+            for (uint64_t i = lo; i < hi && i < bad.load(std::memory_order_relaxed); i++) {  // (rows below a bad one are still checked: the FIRST bad row is reported)
                 int rc = quantize(rows + i * dim, dim, &mins[old_n + i], &deltas[old_n + i],
                                   &codes[old_codes + (size_t)i * dim]);
                 if (rc == HNSW_OK && !std::isfinite(deltas[old_n + i])) rc = HNSW_ERR_NAN_INPUT;

@@ -15,6 +15,7 @@ if norm:  # unit rows: cosine order == L2 order (SURVEY 8d, configs[2])
 print('gen %.1fs' % (time.time() - t), flush=True)
 idx = H.HNSW.new(m, 32, d, kind)
 idx.set_option("inline_budget_mb", 8192)
+if os.environ.get("BMAX"): idx.set_option("gpu_build_batch_max", int(os.environ["BMAX"]))
 if os.environ.get("INLINE") is not None: idx.set_option("inline_rows", int(os.environ["INLINE"]))
 t = time.time(); idx.insert_bulk_device(vs, thr, True); print('device build %.1fs, %d layers' % (time.time() - t, idx.nb_layers()), flush=True)
 del vs
