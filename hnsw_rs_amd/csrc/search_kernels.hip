@@ -2012,9 +2012,8 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
     // expand every unexpanded entry of the list on `layer` (search_layer's loop, searcher.rs:35-95)
     auto expand_all = [&](int layer, uint32_t ef_l, u64 new_flag) __attribute__((always_inline)) {
         const uint32_t S = layer == 0 ? v.S0 : v.S1;
-        while (status == HNSW_OK) {
-            const int cpos = wl.first_unexpanded(lane);
-            if (cpos < 0) break;
+        // the entry at cpos: marked expanded, its id returned
+        auto take = [&](int cpos) __attribute__((always_inline)) -> uint32_t {
             uint32_t cid = 0;
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -2023,16 +2022,48 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
                     if (lane == (cpos & 63)) wl.L[r] |= KEY_EXPANDED;
                 }
             }
-            const uint32_t *row;
-            if (layer == 0) {
-                row = v.adj0 + (size_t)cid * S;
-            } else {
-                const uint32_t ub = v.upper_base[cid];
-                if (ub == HX_EMPTY_SLOT) {
-                    status = HNSW_ERR_NODE_NOT_IN_GRAPH;
+            return cid;
+        };
+        auto row_of = [&](uint32_t cid) __attribute__((always_inline)) -> const uint32_t * {
+            if (layer == 0) return v.adj0 + (size_t)cid * S;
+            const uint32_t ub = v.upper_base[cid];
+            if (ub == HX_EMPTY_SLOT) {
+                status = HNSW_ERR_NODE_NOT_IN_GRAPH;
+                return nullptr;
+            }
+            return v.adj_up + ((size_t)ub + layer - 1) * S;
+        };
+        // The heuristic's extension (new entries are born expanded) expands a FIXED set -- the entries the search
+        // left -- and keeps the union of their neighbours: the order does not matter, so with one lane per row
+        // (f32) and rows of up to 32 slots TWO entries go through one pass, one per half wave, instead of
+        // leaving the upper half idle (the visited insert settles an id both rows hold).
+        const bool two = LPC == 1 && new_flag != 0 && S <= 32;
+        while (status == HNSW_OK) {
+            const int cpos = wl.first_unexpanded(lane);
+            if (cpos < 0) break;
+            const uint32_t cid = take(cpos);
+            const uint32_t *row = row_of(cid);
+            if (row == nullptr) break;
+            if (two) {
+                const int cpos2 = wl.first_unexpanded(lane);
+                const uint32_t *row2 = nullptr;
+                if (cpos2 >= 0) {
+                    row2 = row_of(take(cpos2));
+                    if (row2 == nullptr) break;
+                }
+                const bool upper = lane >= 32;
+                const uint32_t slot = (uint32_t)lane & 31u;
+                uint32_t nb = HX_EMPTY_SLOT;
+                if (slot < S && (!upper || row2 != nullptr)) nb = (upper ? row2 : row)[slot];
+                const bool valid = nb != HX_EMPTY_SLOT && !(nb & HX_OVF_FLAG) && nb != p;
+                const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
+                if (cnt == 0) continue;
+                if (n_vis + cnt > vis_limit) {
+                    status = HNSW_ERR_OVERFLOW;
                     break;
                 }
-                row = v.adj_up + ((size_t)ub + layer - 1) * S;
+                process(nb, valid, true, ef_l, new_flag);
+                continue;
             }
             for (uint32_t c0 = 0; c0 < S && status == HNSW_OK; c0 += CHUNK) {
                 const uint32_t slot = c0 + cslot;
