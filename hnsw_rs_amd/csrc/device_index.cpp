@@ -217,7 +217,10 @@ static void parallel_span(uint64_t lo, uint64_t hi, F f) {
 // link, and packing the whole table first doubles the host memory and adds a pass over it.)
 // fill(row_lo, row_hi, dst): writes rows [row_lo, row_hi) of `unit` bytes each.
 namespace {
+constexpr size_t PIECE_BYTES = 64ull << 20;
 struct PinnedPair {
+    size_t piece_bytes;  // of each buffer: 64 MiB, less for a small index (pinning memory costs time too)
+    explicit PinnedPair(size_t largest_array) : piece_bytes(std::max<size_t>(4096, std::min(PIECE_BYTES, largest_array))) {}
     void *buf[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
     hipStream_t stream = nullptr;
@@ -229,7 +232,6 @@ struct PinnedPair {
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
-constexpr size_t PIECE_BYTES = 64ull << 20;
 }  // namespace
 
 template <class Fill>
@@ -237,11 +239,11 @@ static int upload_pieces(PinnedPair &pp, void *dst, uint64_t n_rows, size_t unit
     if (!pp.stream) {
         HIP_TRY(hipStreamCreateWithFlags(&pp.stream, hipStreamNonBlocking));
         for (int i = 0; i < 2; i++) {
-            HIP_TRY(hipHostMalloc(&pp.buf[i], PIECE_BYTES, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc(&pp.buf[i], pp.piece_bytes, hipHostMallocDefault));
             HIP_TRY(hipEventCreateWithFlags(&pp.ev[i], hipEventDisableTiming));
         }
     }
-    const uint64_t per = std::max<uint64_t>(1, PIECE_BYTES / unit);
+    const uint64_t per = std::max<uint64_t>(1, pp.piece_bytes / unit);
     int k = 0;
     for (uint64_t lo = 0; lo < n_rows; lo += per, k ^= 1) {
         const uint64_t hi = std::min(n_rows, lo + per);
@@ -322,7 +324,7 @@ int DeviceIndex::upload(const HostIndex &idx, int dev) {
     if ((rc = dev_alloc(0, (size_t)N * v.row_stride)) != HNSW_OK) return rc;
     if ((rc = dev_alloc(1, (size_t)N * v.S0 * 4)) != HNSW_OK) return rc;
     {
-        PinnedPair pp;
+        PinnedPair pp(std::max((size_t)N * v.row_stride, (size_t)N * v.S0 * 4));
         if (want_fat) rows_h.resize((size_t)N * v.row_stride);
         rc = upload_pieces(pp, bufs_[0], N, v.row_stride, [&](uint64_t lo, uint64_t hi, unsigned char *dst) {
             parallel_span(lo, hi, [&](uint64_t a, uint64_t b) {
