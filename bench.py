@@ -397,7 +397,9 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_measured_at": traffic_from,
         "kernel": (("hx_lean_f32_kernel" if kind == H.VEC_F32 else "hx_lean_q8_kernel")
-                   if d == 100 and ef <= 128 and os.environ.get("HNSW_MI355X_LEAN") != "0" and
+                   if (d == 100 or (d == 128 and kind == H.VEC_F32 and os.environ.get("HNSW_MI355X_LEAN_128") != "0"))
+                   and ef <= (128 if os.environ.get("HNSW_MI355X_LEAN_WIDE") == "0" else 256)
+                   and os.environ.get("HNSW_MI355X_LEAN") != "0" and
                    (kind == H.VEC_F32 or os.environ.get("HNSW_MI355X_LEAN_Q8") != "0") else "hx_search_kernel"),
         "kernel_ms": round(kern_ms, 5),
         "kernel_ms_note": "average launch duration: one HIP event pair around the K launches of the timed region, / K",

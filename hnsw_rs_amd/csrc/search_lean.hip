@@ -1354,7 +1354,7 @@ int launch_lean_one(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
 }  // namespace
 
 // Whether the lean kernel serves this search: the whole ann_by_vector descent over f32 rows of a
-// dimension it is built for, lists of at most two registers.  HNSW_MI355X_LEAN=0 turns it off (A/B).
+// dimension it is built for, lists of up to four registers (ef <= 256).  HNSW_MI355X_LEAN=0 turns it off (A/B).
 bool lean_applicable(const DevView &v, const SearchArgs &a, uint32_t ef_max) {
     static const bool enabled = !(getenv("HNSW_MI355X_LEAN") && atoi(getenv("HNSW_MI355X_LEAN")) == 0);
     if (!enabled) return false;
@@ -1366,7 +1366,10 @@ bool lean_applicable(const DevView &v, const SearchArgs &a, uint32_t ef_max) {
     if (!f32_ok && !q8_ok) return false;
     if (a.entries != nullptr || a.layer_lo != 0 || a.layer_hi != (int32_t)v.nb_layers - 1) return false;
     if (a.layer_hi > 0 && a.ef_upper != 1) return false;
-    if (v.S0 > 32 || v.S1 > 64 || ef_max > 128 || (a.flags & 1u)) return false;
+    // lists: one register (ef <= 64), head + tail (<= 128), four interleaved registers (<= 256, HNSW_MI355X_LEAN_WIDE=0
+    // sends those to the generic kernel, for A/B runs)
+    static const bool wide = !(getenv("HNSW_MI355X_LEAN_WIDE") && atoi(getenv("HNSW_MI355X_LEAN_WIDE")) == 0);
+    if (v.S0 > 32 || v.S1 > 64 || ef_max > (wide ? 256u : 128u) || (a.flags & 1u)) return false;
     return true;
 }
 
@@ -1393,10 +1396,11 @@ int launch_lean(const DevView &v, const SearchArgs &s, uint32_t nblocks, uint32_
     a.n = s.n;
     a.slots_log2 = slots_log2;
     a.dbg = s.dbg;
-    // 64 < ef <= 128: head + tail list (HNSW_MI355X_LIST=interleaved: round 2's two-register list, for A/B runs)
+    // 64 < ef <= 128: head + tail list (HNSW_MI355X_LIST=interleaved: round 2's two-register list, for A/B runs); 128 < ef <= 256: four interleaved registers
     static const bool interleaved = getenv("HNSW_MI355X_LIST") && getenv("HNSW_MI355X_LIST")[0] == 'i';
     if (v.kind == HNSW_VEC_QUANT8) {
         if (a.ef <= 64) return launch_lean_q8<Lst<1>>(a, nblocks, stream);
+        if (a.ef > 128) return launch_lean_q8<Lst<4>>(a, nblocks, stream);
         if (interleaved) return launch_lean_q8<Lst<2>>(a, nblocks, stream);
         return launch_lean_q8<LstHT>(a, nblocks, stream);
     }
@@ -1410,9 +1414,11 @@ int launch_lean(const DevView &v, const SearchArgs &s, uint32_t nblocks, uint32_
         }();
         const bool few = nblocks <= 4 * n_cu;  // at most one wave per SIMD: the four-stage build (see the kernel)
         if (a.ef <= 64) return few ? launch_lean_one<128, Lst<1>, 4>(a, nblocks, stream) : launch_lean_one<128, Lst<1>, 2>(a, nblocks, stream);
+        if (a.ef > 128) return launch_lean_one<128, Lst<4>, 2>(a, nblocks, stream);
         return few ? launch_lean_one<128, LstHT, 4>(a, nblocks, stream) : launch_lean_one<128, LstHT, 2>(a, nblocks, stream);
     }
     if (a.ef <= 64) return launch_lean_one<100, Lst<1>>(a, nblocks, stream);
+    if (a.ef > 128) return launch_lean_one<100, Lst<4>>(a, nblocks, stream);
     if (interleaved) return launch_lean_one<100, Lst<2>>(a, nblocks, stream);
     return launch_lean_one<100, LstHT>(a, nblocks, stream);
 }

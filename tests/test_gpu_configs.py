@@ -35,10 +35,10 @@ def f32_100d():
     return device_built(24000, 100, 16, H.VEC_F32)
 
 
-@pytest.mark.parametrize("ef", [64, 68, 96, 128, 129, 256])
+@pytest.mark.parametrize("ef", [64, 68, 96, 128, 129, 192, 256, 257])
 def test_the_timed_f32_kernel(f32_100d, ef):
-    """configs[1]: 100d f32, M = 16 -- the lean kernel with one (ef <= 64) and two (<= 128) list registers,
-    the generic kernel beyond"""
+    """configs[1]: 100d f32, M = 16 -- the lean kernel with one list register (ef <= 64), head + tail (<= 128) and
+    four interleaved registers (<= 256), the generic kernel beyond"""
     idx, orc, qs = f32_100d
     assert_search_equal(idx.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=8), "f32 100d ef=%d" % ef)
 
@@ -56,7 +56,7 @@ def test_the_generic_f32_kernel_still_agrees(f32_100d):
         "lv = O.draw_levels(n, m, 7)\n"
         "idx = H.HNSW.new(m, 32, d, H.VEC_F32); idx.insert_bulk_device(vs, 8, False, levels=lv)\n"
         "orc = oracle_from_product(idx, vs, lv)\n"
-        "for ef in (64, 68, 128):\n"
+        "for ef in (64, 68, 128, 192, 256):\n"
         "    assert_search_equal(idx.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=8), 'generic ef=%%d' %% ef)\n"
         "print('generic ok')\n" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HNSW_MI355X_LEAN="0"),
@@ -65,14 +65,27 @@ def test_the_generic_f32_kernel_still_agrees(f32_100d):
 
 
 @pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
+def test_lean_kernels_with_the_four_register_list(kind):
+    """129 <= ef <= 256 at d = 100: the lean kernels with four interleaved list registers (round 3; the generic
+    kernel served these before), top-n reaching into every register"""
+    idx, orc, qs = device_built(20000, 100, 16, kind)
+    for ef in (129, 160, 255, 256):
+        assert_search_equal(idx.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=8), "ef=%d" % ef)
+    assert_search_equal(idx.search_batch(qs[:64], 250, 256), orc.search_batch(qs[:64], 250, 256, nthreads=8), "n=250")
+    assert_search_equal(idx.search_batch(qs[:64], 300, 200), orc.search_batch(qs[:64], 300, 200, nthreads=8), "n > ef")
+
+
+@pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
 def test_128d(kind):
     """configs[3] dimension"""
     idx, orc, qs = device_built(20000, 128, 16, kind)
-    # f32: ef <= 128 runs the lean kernel with the cooperative row gather (one list register up to 64, head +
-    # tail above), 200 the generic kernel; n = 100 reaches into the tail register
-    for ef in (1, 10, 64, 65, 100, 128, 200):
+    # f32: ef <= 256 runs the lean kernel with the cooperative row gather (one list register up to 64, head +
+    # tail up to 128, four interleaved registers up to 256), 300 the generic kernel; n = 100 reaches into the
+    # tail register, n = 200 into the third and fourth of the interleaved ones
+    for ef in (1, 10, 64, 65, 100, 128, 129, 200, 256, 300):
         assert_search_equal(idx.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=8), "128d ef=%d" % ef)
     assert_search_equal(idx.search_batch(qs[:64], 100, 120), orc.search_batch(qs[:64], 100, 120, nthreads=8), "128d n=100")
+    assert_search_equal(idx.search_batch(qs[:64], 200, 230), orc.search_batch(qs[:64], 200, 230, nthreads=8), "128d n=200")
 
 
 @pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])

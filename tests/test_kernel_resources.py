@@ -31,8 +31,9 @@ def test_lean_kernels_fit_two_waves_per_simd_without_agprs_or_scratch(tmp_path):
         if m and cur is not None:
             cur[m.group(1).strip()] = int(m.group(2))
     timed = {k: v for k, v in kernels.items() if "hx_lean_f32_kernel" in k or "hx_lean_q8_kernel" in k}
-    # f32 100d and quant8: one register, head + tail, interleaved two (A/B); f32 128d (cooperative gather): one register, head + tail
-    assert len(timed) == 10, sorted(kernels)  # (d = 128: two stage depths each)
+    # f32 100d and quant8: one register, head + tail, interleaved two (A/B), interleaved four (ef 129..256); f32 128d
+    # (cooperative gather): one register and head + tail at two stage depths each, interleaved four
+    assert len(timed) == 13, sorted(kernels)
     for name, r in timed.items():
         assert r.get("ScratchSize", 0) == 0 and r.get("VGPRs Spill", 0) == 0, (name, r)
         if "ILi128E" in name:
@@ -43,4 +44,4 @@ def test_lean_kernels_fit_two_waves_per_simd_without_agprs_or_scratch(tmp_path):
             continue
         assert r.get("AGPRs", 0) == 0, (name, r)
         assert r.get("Occupancy", 0) >= 2, (name, r)
-        assert r.get("VGPRs", 999) <= 240, (name, r)
+        assert r.get("VGPRs", 999) <= 248, (name, r)  # (the four-register list: 244)
