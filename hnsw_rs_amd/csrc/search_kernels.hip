@@ -2701,7 +2701,11 @@ int launch_scatter_rows(uint32_t *dst, uint32_t S, const uint32_t *d_row_index, 
 uint32_t default_slots_log2(uint32_t ef, uint32_t s0) {
     const uint64_t e = (uint64_t)ef * std::max(s0, 8u) / 32u;  // ef in units of 32-slot rows
     if (e <= 112) return 12;  // 4096 slots, 16 KiB: limit 3072
-    if (e <= 256) return 13;  // 8192 slots, 32 KiB: limit 6144
+    // 8192 slots, 32 KiB: limit 6144.  Up to ef 320: a search visits ~ 11 ef + 500 ids on average and up to 1.4 x that
+    // (1M x 100d: 3.7 k at ef 300, no query of 8192 fills the table; at 384 one in twenty does and would run again with
+    // the next size), and four waves per CU -- a whole batch of 1024 at once -- need the table to stay at 32 KiB
+    // (ef 300, batch 1024: 0.86 ms against 1.50 ms with 64 KiB)
+    if (e <= 320) return 13;
     if (e <= 576) return 14;  // 64 KiB: limit 12288
     if (ef <= 64 * HX_MAX_R_WIDE) return 15;  // 128 KiB
     // the HBM-resident table of hx_search_spill_kernel (limit: one half): about 30 visited ids per list entry

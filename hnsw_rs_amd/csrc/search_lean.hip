@@ -1369,7 +1369,8 @@ bool lean_applicable(const DevView &v, const SearchArgs &a, uint32_t ef_max) {
     // lists: one register (ef <= 64), head + tail (<= 128), four interleaved registers (<= 256, HNSW_MI355X_LEAN_WIDE=0
     // sends those to the generic kernel, for A/B runs)
     static const bool wide = !(getenv("HNSW_MI355X_LEAN_WIDE") && atoi(getenv("HNSW_MI355X_LEAN_WIDE")) == 0);
-    if (v.S0 > 32 || v.S1 > 64 || ef_max > (wide ? 256u : 128u) || (a.flags & 1u)) return false;
+    // (eight registers, ef <= 512: f32 100d only -- x 1.28 against the generic kernel; quant8 gains nothing there)
+    if (v.S0 > 32 || v.S1 > 64 || ef_max > (wide ? (v.dim == 100 && v.kind == HNSW_VEC_F32 ? 512u : 256u) : 128u) || (a.flags & 1u)) return false;
     return true;
 }
 
@@ -1418,6 +1419,7 @@ int launch_lean(const DevView &v, const SearchArgs &s, uint32_t nblocks, uint32_
         return few ? launch_lean_one<128, LstHT, 4>(a, nblocks, stream) : launch_lean_one<128, LstHT, 2>(a, nblocks, stream);
     }
     if (a.ef <= 64) return launch_lean_one<100, Lst<1>>(a, nblocks, stream);
+    if (a.ef > 256) return launch_lean_one<100, Lst<8>>(a, nblocks, stream);
     if (a.ef > 128) return launch_lean_one<100, Lst<4>>(a, nblocks, stream);
     if (interleaved) return launch_lean_one<100, Lst<2>>(a, nblocks, stream);
     return launch_lean_one<100, LstHT>(a, nblocks, stream);

@@ -23,4 +23,5 @@ for ef in efs:
         for b in range(8): run(b)
     e1.record(); torch.cuda.synchronize(); ms = e0.elapsed_time(e1) / 32
     s = st.cpu().numpy()
+    if (s[:, 3] != 0).any(): print('   statuses:', dict(zip(*np.unique(s[:, 3], return_counts=True))))
     print('kind=%s ef=%d  %.4f ms/batch  %.2f M q/s  n_dist %.0f n_exp %.1f  us/exp %.2f' % (sys.argv[1], ef, ms, B / ms / 1e3, s[:, 0].mean(), s[:, 1].mean(), ms * 1e3 / s[:, 1].mean()), flush=True)

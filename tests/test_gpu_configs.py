@@ -35,10 +35,10 @@ def f32_100d():
     return device_built(24000, 100, 16, H.VEC_F32)
 
 
-@pytest.mark.parametrize("ef", [64, 68, 96, 128, 129, 192, 256, 257])
+@pytest.mark.parametrize("ef", [64, 68, 96, 128, 129, 192, 256, 257, 400, 512, 513])
 def test_the_timed_f32_kernel(f32_100d, ef):
-    """configs[1]: 100d f32, M = 16 -- the lean kernel with one list register (ef <= 64), head + tail (<= 128) and
-    four interleaved registers (<= 256), the generic kernel beyond"""
+    """configs[1]: 100d f32, M = 16 -- the lean kernel with one list register (ef <= 64), head + tail (<= 128), four
+    and eight interleaved registers (<= 256, <= 512), the generic kernel beyond"""
     idx, orc, qs = f32_100d
     assert_search_equal(idx.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=8), "f32 100d ef=%d" % ef)
 
@@ -66,13 +66,14 @@ def test_the_generic_f32_kernel_still_agrees(f32_100d):
 
 @pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
 def test_lean_kernels_with_the_four_register_list(kind):
-    """129 <= ef <= 256 at d = 100: the lean kernels with four interleaved list registers (round 3; the generic
-    kernel served these before), top-n reaching into every register"""
+    """129 <= ef <= 512 at d = 100: the lean kernels with four and eight interleaved list registers (round 3; the
+    generic kernel served these before), top-n reaching into every register"""
     idx, orc, qs = device_built(20000, 100, 16, kind)
-    for ef in (129, 160, 255, 256):
+    for ef in (129, 160, 255, 256, 257, 300, 512):
         assert_search_equal(idx.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=8), "ef=%d" % ef)
     assert_search_equal(idx.search_batch(qs[:64], 250, 256), orc.search_batch(qs[:64], 250, 256, nthreads=8), "n=250")
     assert_search_equal(idx.search_batch(qs[:64], 300, 200), orc.search_batch(qs[:64], 300, 200, nthreads=8), "n > ef")
+    assert_search_equal(idx.search_batch(qs[:64], 500, 512), orc.search_batch(qs[:64], 500, 512, nthreads=8), "n=500")
 
 
 @pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])

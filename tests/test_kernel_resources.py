@@ -33,10 +33,10 @@ def test_lean_kernels_fit_two_waves_per_simd_without_agprs_or_scratch(tmp_path):
     timed = {k: v for k, v in kernels.items() if "hx_lean_f32_kernel" in k or "hx_lean_q8_kernel" in k}
     # f32 100d and quant8: one register, head + tail, interleaved two (A/B), interleaved four (ef 129..256); f32 128d
     # (cooperative gather): one register and head + tail at two stage depths each, interleaved four
-    assert len(timed) == 13, sorted(kernels)
+    assert len(timed) == 14, sorted(kernels)  # (+ eight interleaved registers for ef 257..512, f32 100d)
     for name, r in timed.items():
         assert r.get("ScratchSize", 0) == 0 and r.get("VGPRs Spill", 0) == 0, (name, r)
-        if "ILi128E" in name:
+        if "ILi128E" in name or ("hx_lean_f32_kernel" in name and "LstILi8E" in name):
             # d = 128 holds the query's 128 values in registers beside the gather's stage ring: it sits AT the
             # 256-register line (a couple of values parked in AGPRs), which costs nothing at the metric's one wave
             # per SIMD; what must not come back is scratch or a ring that lives in AGPRs
