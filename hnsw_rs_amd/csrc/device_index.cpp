@@ -222,12 +222,18 @@ struct PinnedPair {
     size_t piece_bytes;  // of each buffer: 64 MiB, less for a small index (pinning memory costs time too)
     explicit PinnedPair(size_t largest_array) : piece_bytes(std::max<size_t>(4096, std::min(PIECE_BYTES, largest_array))) {}
     void *buf[2] = {nullptr, nullptr};
+    bool pinned = true;  // false: the host refused to pin memory (a small memlock limit); plain buffers, blocking copies
     hipEvent_t ev[2] = {nullptr, nullptr};
     hipStream_t stream = nullptr;
     ~PinnedPair() {
         for (int i = 0; i < 2; i++) {
             if (ev[i]) (void)hipEventDestroy(ev[i]);
-            if (buf[i]) (void)hipHostFree(buf[i]);
+            if (buf[i]) {
+                if (pinned)
+                    (void)hipHostFree(buf[i]);
+                else
+                    free(buf[i]);
+            }
         }
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -238,10 +244,29 @@ template <class Fill>
 static int upload_pieces(PinnedPair &pp, void *dst, uint64_t n_rows, size_t unit, Fill fill) {
     if (!pp.stream) {
         HIP_TRY(hipStreamCreateWithFlags(&pp.stream, hipStreamNonBlocking));
-        for (int i = 0; i < 2; i++) {
-            HIP_TRY(hipHostMalloc(&pp.buf[i], pp.piece_bytes, hipHostMallocDefault));
-            HIP_TRY(hipEventCreateWithFlags(&pp.ev[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&pp.ev[i], hipEventDisableTiming));
+        const bool refuse = getenv("HNSW_MI355X_NO_PINNED") && atoi(getenv("HNSW_MI355X_NO_PINNED")) != 0;  // (tests)
+        if (refuse || hipHostMalloc(&pp.buf[0], pp.piece_bytes, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&pp.buf[1], pp.piece_bytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            if (pp.buf[0]) (void)hipHostFree(pp.buf[0]);
+            pp.pinned = false;
+            pp.buf[0] = malloc(pp.piece_bytes);
+            pp.buf[1] = nullptr;
+            if (!pp.buf[0]) {
+                set_error("upload: no memory for a %zu-byte staging buffer", pp.piece_bytes);
+                return HNSW_ERR_OOM;
+            }
         }
+    }
+    if (!pp.pinned) {  // one plain buffer, one blocking copy per piece
+        const uint64_t per1 = std::max<uint64_t>(1, pp.piece_bytes / unit);
+        for (uint64_t lo = 0; lo < n_rows; lo += per1) {
+            const uint64_t hi = std::min(n_rows, lo + per1);
+            fill(lo, hi, static_cast<unsigned char *>(pp.buf[0]));
+            HIP_TRY(hipMemcpy(static_cast<unsigned char *>(dst) + lo * unit, pp.buf[0], (hi - lo) * unit, hipMemcpyHostToDevice));
+        }
+        return HNSW_OK;
     }
     const uint64_t per = std::max<uint64_t>(1, pp.piece_bytes / unit);
     int k = 0;

@@ -64,6 +64,27 @@ def test_the_generic_f32_kernel_still_agrees(f32_100d):
     assert out.returncode == 0 and "generic ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_upload_without_pinned_staging_memory():
+    """the snapshot upload streams through pinned buffers; where the host refuses to pin memory it falls back to a
+    plain buffer and blocking copies (HNSW_MI355X_NO_PINNED=1 forces that) -- same snapshot, same answers"""
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import hnsw_rs_amd as H\n"
+        "from oracle import oracle_py as O\n"
+        "from tests.util import oracle_from_product, assert_search_equal\n"
+        "n, d, m = 30000, 100, 16\n"
+        "vs = H.synth_rows(0, 0x5EED0001, 0, n, d); qs = H.synth_rows(0, 0x5EED0002, 0, 64, d)\n"
+        "lv = O.draw_levels(n, m, 11)\n"
+        "for kind in (H.VEC_F32, H.VEC_QUANT8):\n"
+        "    idx = H.HNSW.new(m, 32, d, kind); idx.insert_bulk(vs, 8, False, levels=lv)\n"
+        "    orc = oracle_from_product(idx, vs, lv)\n"
+        "    assert_search_equal(idx.search_batch(qs, 10, 64), orc.search_batch(qs, 10, 64, nthreads=8), 'kind %%d' %% kind)\n"
+        "print('plain staging ok')\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HNSW_MI355X_NO_PINNED="1"),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "plain staging ok" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
 def test_lean_kernels_with_the_four_register_list(kind):
     """129 <= ef <= 512 at d = 100: the lean kernels with four and eight interleaved list registers (round 3; the
