@@ -948,34 +948,34 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     }
     std::vector<uint64_t> refusals(counts[2]);
     if (counts[2]) HIP_TRY(hipMemcpy(refusals.data(), dRef.p, (size_t)counts[2] * 8, hipMemcpyDeviceToHost));
-    {
-        std::vector<uint32_t> buf;
-        for (int pass = 0; pass < 2; pass++) {
-            std::vector<std::vector<NodeID>> &rowsv = pass == 0 ? host.adj0 : host.adj_up;
-            const uint32_t S = pass == 0 ? v.S0 : v.S1;
-            const size_t R = rowsv.size();
-            if (R == 0) continue;
-            buf.resize(R * (size_t)S);
-            HIP_TRY(hipMemcpy(buf.data(), pass == 0 ? h->dev.adj0_mut() : h->dev.adj_up_mut(), R * (size_t)S * 4,
-                              hipMemcpyDeviceToHost));
-            auto fill = [&](size_t lo, size_t hi) {
-                for (size_t r = lo; r < hi; r++) {
-                    const uint32_t *src = &buf[r * (size_t)S];
+    for (int pass = 0; pass < 2; pass++) {
+        std::vector<std::vector<NodeID>> &rowsv = pass == 0 ? host.adj0 : host.adj_up;
+        const uint32_t S = pass == 0 ? v.S0 : v.S1;
+        const size_t R = rowsv.size();
+        if (R == 0) continue;
+        // pieces of the array arrive through pinned buffers; the threads turn each into the host's rows while
+        // the next one is on the wire
+        rc = h->dev.read_adjacency(pass, R, [&](uint64_t plo, uint64_t phi, const uint32_t *data) {
+            auto fill = [&](uint64_t lo, uint64_t hi) {
+                for (uint64_t r = lo; r < hi; r++) {
+                    const uint32_t *src = data + (r - plo) * (size_t)S;
                     std::vector<NodeID> &dst = rowsv[r];
                     dst.clear();
                     for (uint32_t k = 0; k < S; k++)
                         if (src[k] != UINT32_MAX) dst.push_back(src[k]);
                 }
             };
-            const unsigned nt = (unsigned)std::min<size_t>(nb_threads, std::max<size_t>(1, R / 65536));
+            const uint64_t cnt = phi - plo;
+            const unsigned nt = (unsigned)std::min<uint64_t>(nb_threads, std::max<uint64_t>(1, cnt / 16384));
             if (nt <= 1) {
-                fill(0, R);
+                fill(plo, phi);
             } else {
                 std::vector<std::thread> th;
-                for (unsigned t = 0; t < nt; t++) th.emplace_back(fill, R * t / nt, R * (t + 1) / nt);
+                for (unsigned t = 0; t < nt; t++) th.emplace_back(fill, plo + cnt * t / nt, plo + cnt * (t + 1) / nt);
                 for (auto &t : th) t.join();
             }
-        }
+        });
+        if (rc != HNSW_OK) return rc;
     }
     // an edge x -> nb that stayed because it was x's last one: restore nb -> x (graph.rs:85-94 keeps both)
     refusals.insert(refusals.end(), restore.begin(), restore.end());

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -279,6 +280,56 @@ static int upload_pieces(PinnedPair &pp, void *dst, uint64_t n_rows, size_t unit
         HIP_TRY(hipEventRecord(pp.ev[k], pp.stream));
     }
     HIP_TRY(hipStreamSynchronize(pp.stream));
+    return HNSW_OK;
+}
+
+int DeviceIndex::read_adjacency(int which, uint64_t n_rows,
+                                const std::function<void(uint64_t, uint64_t, const uint32_t *)> &consume) {
+    if (!valid || n_rows == 0) return HNSW_OK;
+    const uint32_t S = which == 0 ? view.S0 : view.S1;
+    const size_t unit = (size_t)S * 4;
+    const unsigned char *src = static_cast<const unsigned char *>(bufs_[which == 0 ? 1 : 2]);
+    HIP_TRY(hipSetDevice(device));
+    PinnedPair pp(n_rows * unit);
+    HIP_TRY(hipStreamCreateWithFlags(&pp.stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&pp.ev[i], hipEventDisableTiming));
+    const bool refuse = getenv("HNSW_MI355X_NO_PINNED") && atoi(getenv("HNSW_MI355X_NO_PINNED")) != 0;
+    if (refuse || hipHostMalloc(&pp.buf[0], pp.piece_bytes, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(&pp.buf[1], pp.piece_bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        if (pp.buf[0]) (void)hipHostFree(pp.buf[0]);
+        pp.pinned = false;
+        pp.buf[0] = malloc(pp.piece_bytes);
+        pp.buf[1] = nullptr;
+        if (!pp.buf[0]) {
+            set_error("read-back: no memory for a %zu-byte staging buffer", pp.piece_bytes);
+            return HNSW_ERR_OOM;
+        }
+    }
+    const uint64_t per = std::max<uint64_t>(1, pp.piece_bytes / unit);
+    if (!pp.pinned) {
+        for (uint64_t lo = 0; lo < n_rows; lo += per) {
+            const uint64_t hi = std::min(n_rows, lo + per);
+            HIP_TRY(hipMemcpy(pp.buf[0], src + lo * unit, (hi - lo) * unit, hipMemcpyDeviceToHost));
+            consume(lo, hi, static_cast<const uint32_t *>(pp.buf[0]));
+        }
+        return HNSW_OK;
+    }
+    // piece k + 1 is on the wire while the host consumes piece k
+    auto request = [&](uint64_t lo, int k) -> int {
+        const uint64_t hi = std::min(n_rows, lo + per);
+        HIP_TRY(hipMemcpyAsync(pp.buf[k], src + lo * unit, (hi - lo) * unit, hipMemcpyDeviceToHost, pp.stream));
+        HIP_TRY(hipEventRecord(pp.ev[k], pp.stream));
+        return HNSW_OK;
+    };
+    int rc = request(0, 0), k = 0;
+    if (rc != HNSW_OK) return rc;
+    for (uint64_t lo = 0; lo < n_rows; lo += per, k ^= 1) {
+        const uint64_t hi = std::min(n_rows, lo + per);
+        if (hi < n_rows && (rc = request(hi, k ^ 1)) != HNSW_OK) return rc;
+        HIP_TRY(hipEventSynchronize(pp.ev[k]));
+        consume(lo, hi, static_cast<const uint32_t *>(pp.buf[k]));
+    }
     return HNSW_OK;
 }
 
