@@ -650,7 +650,7 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     const uint64_t n_before = host.len();
     std::vector<NodeID> ids;
     const auto t_enter = std::chrono::steady_clock::now();
-    int rc = host.store_points(rows, n, levels, &ids, nb_threads);
+    int rc = host.store_points(rows, n, levels, &ids, nb_threads, /*reserve_rows=*/false);
     if (rc != HNSW_OK) return rc;
     const auto t_stored = std::chrono::steady_clock::now();
     host.prepare_build();
@@ -744,6 +744,20 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     double t_ins = 0, t_conn = 0;
     size_t n_batches = 0, n_req = 0, n_rem = 0, n_again = 0;
     uint32_t counts[4];
+    // the capacity of the new points' host rows (one small allocation each) is reserved by other threads while the
+    // GPU runs the batches: nothing touches the host graph until the read-back below
+    struct RowReserve {
+        std::thread t;
+        ~RowReserve() {
+            if (t.joinable()) t.join();
+        }
+    } row_reserve;
+    {
+        hx::HostIndex *hp = &host;
+        const NodeID first_new = (NodeID)n_before;
+        const uint32_t threads = std::max(1u, nb_threads / 2);
+        row_reserve.t = std::thread([hp, first_new, n, threads] { hp->reserve_layer0_rows(first_new, n, threads); });
+    }
     const auto t_loop0 = std::chrono::steady_clock::now();
 
     while (pos < order.size()) {
@@ -940,6 +954,7 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     }
 
     // ---- the host graph from the device arrays ----
+    if (row_reserve.t.joinable()) row_reserve.t.join();
     const auto t_sync0 = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpy(counts, dCnt.p, 16, hipMemcpyDeviceToHost));
     if (counts[3] != 0 || counts[2] > REF_CAP) {
@@ -957,12 +972,13 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         // the next one is on the wire
         rc = h->dev.read_adjacency(pass, R, [&](uint64_t plo, uint64_t phi, const uint32_t *data) {
             auto fill = [&](uint64_t lo, uint64_t hi) {
+                std::vector<NodeID> ids_of_row(S);
                 for (uint64_t r = lo; r < hi; r++) {
                     const uint32_t *src = data + (r - plo) * (size_t)S;
-                    std::vector<NodeID> &dst = rowsv[r];
-                    dst.clear();
+                    uint32_t deg = 0;
                     for (uint32_t k = 0; k < S; k++)
-                        if (src[k] != UINT32_MAX) dst.push_back(src[k]);
+                        if (src[k] != UINT32_MAX) ids_of_row[deg++] = src[k];
+                    rowsv[r].assign(ids_of_row.begin(), ids_of_row.begin() + deg);  // one allocation of the row's size
                 }
             };
             const uint64_t cnt = phi - plo;

@@ -672,7 +672,7 @@ static void advise_huge_pages(void *p, size_t nbytes) {
 }
 
 int HostIndex::store_points(const float *rows, uint64_t n, const uint8_t *levels_in,
-                            std::vector<NodeID> *ids_out, uint32_t nb_threads) {
+                            std::vector<NodeID> *ids_out, uint32_t nb_threads, bool reserve_rows) {
     if (n == 0) {
         set_error("no vectors given");
         return HNSW_ERR_EMPTY;
@@ -775,10 +775,7 @@ int HostIndex::store_points(const float *rows, uint64_t n, const uint8_t *levels
         }
         for (uint32_t l = 0; l <= level; l++) layer_nodes[l].push_back(id);
     }
-    run([&](uint64_t lo, uint64_t hi) {
-        const size_t cap = layer_m(0) + 2;
-        for (uint64_t i = lo; i < hi; i++) adj0[first + i].reserve(cap);
-    });
+    if (reserve_rows) reserve_layer0_rows(first, n, nb_threads);
     // template.rs:283-290: ep = first key of the top layer (hash order there; smallest id here)
     params.ep = layer_nodes.back().front();
     if (ids_out) {
@@ -787,6 +784,21 @@ int HostIndex::store_points(const float *rows, uint64_t n, const uint8_t *levels
     }
     version++;
     return HNSW_OK;
+}
+
+void HostIndex::reserve_layer0_rows(NodeID first, uint64_t n, uint32_t nb_threads) {
+    const size_t cap = layer_m(0) + 2;
+    const unsigned nt = (unsigned)std::min<uint64_t>(std::max(1u, nb_threads), std::max<uint64_t>(1, n / 4096));
+    auto work = [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++) adj0[first + i].reserve(cap);
+    };
+    if (nt <= 1) {
+        work(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+    for (auto &t : th) t.join();
 }
 
 // HNSW::insert_bulk, template.rs:388-444
