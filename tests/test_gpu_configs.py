@@ -278,6 +278,30 @@ def test_device_build_batch_schedule_options():
         idx.set_option("gpu_build_batch_max", 0)
 
 
+def test_device_build_with_batches_of_32768_points():
+    """the largest batch the build takes ("gpu_build_batch_max" 32768, what bench.py --config 4 asks for): with
+    div 2 a 100k-point build reaches it; the graph is valid, recall is that of the default schedule, the search is
+    the oracle's, and the small-visited-table-first launches repeat their overflowing points instead of sending
+    them to the CPU path (the build is still complete)"""
+    n, d, m = 100000, 32, 16
+    vs = H.synth_rows(0, 0x5EED0001, 0, n, d, 8)
+    qs = H.synth_rows(0, 0x5EED0002, 0, 256, d)
+    lv = O.draw_levels(n, m, 0x5EED0003)
+    recalls = []
+    for bmax, bdiv in ((8192, 8), (32768, 2)):
+        idx = H.HNSW.new(m, 32, d, H.VEC_F32)
+        idx.set_option("gpu_build_batch_max", bmax)
+        idx.set_option("gpu_build_batch_div", bdiv)
+        idx.insert_bulk_device(vs, 8, False, levels=lv)
+        assert idx.len() == n and idx.assert_param_compliance()
+        orc = oracle_from_product(idx, vs, lv)
+        got = idx.search_batch(qs, 10, 64)
+        assert_search_equal(got, orc.search_batch(qs, 10, 64, nthreads=8), "schedule %d:%d" % (bmax, bdiv))
+        truth, _ = idx.brute_force(qs, 10)
+        recalls.append(sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(got[0], truth)) / 2560.0)
+    assert recalls[1] > recalls[0] - 0.02 and min(recalls) > 0.9, recalls
+
+
 @pytest.mark.parametrize("kind", [H.VEC_F32, H.VEC_QUANT8])
 def test_full_size_properties_1m_x_100d(kind):
     """configs[1] at its full size (1M x 100d, M = 16, efSearch 64 / 68, batches of 1024): the oracle is checked
