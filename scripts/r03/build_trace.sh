@@ -17,6 +17,6 @@ tot = 0
 for i, r in enumerate(rows):
     ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     tot += ms
-    if i % 8 == 0: print("batch %3d grid %8s  %.3f ms" % (i, r["Grid_Size"], ms))
+    if i % 8 == 0: print("batch %3d grid %8s  %.3f ms" % (i, r.get("Grid_Size", r.get("Grid_Size_X")), ms))
 print("total insert kernel ms", tot)
 PY
