@@ -480,25 +480,32 @@ class Inserter {
         cand = selected;
         cand_head = 0;
         selected.clear();
-        // extend_candidates_with_neighbors, results.rs:122-146
+        // extend_candidates_with_neighbors, results.rs:122-146.  The reference evaluates every neighbour of every
+        // candidate and lets the set drop the repeats; an id's distance to the point is the same each time, so
+        // each id is evaluated once here (the visited stamps are free between two searches): the same set, a
+        // third of the distances and of the sort
         tmp.clear();
+        for (const Dist &c0 : cand) visit(c0.id);
         for (const Dist &node : cand) {
             if (!idx.neighbors_vec(layer, node.id, &nb)) {
                 set_error("Node %u is not in the Graph", node.id);
                 return HNSW_ERR_NODE_NOT_IN_GRAPH;
             }
-            for (NodeID n : nb)
+            fresh.clear();
+            for (NodeID n : nb) {
                 if (n >= idx.len()) return HNSW_ERR_ARG;
-            dists.resize(nb.size());
-            idx.dist2many(point, nb.data(), nb.size(), dists.data());  // points.distance(point.id, neighbor)
-            for (size_t k = 0; k < nb.size(); k++) {
+                if (visit(n)) fresh.push_back(n);
+            }
+            dists.resize(fresh.size());
+            idx.dist2many(point, fresh.data(), fresh.size(), dists.data());  // points.distance(point.id, neighbor)
+            for (size_t k = 0; k < fresh.size(); k++) {
                 if (std::isnan(dists[k])) return HNSW_ERR_NAN_INPUT;
-                tmp.push_back(Dist{nb[k], dists[k]});
+                tmp.push_back(Dist{fresh[k], dists[k]});
             }
         }
+        visited_clear();
         cand.insert(cand.end(), tmp.begin(), tmp.end());
-        std::sort(cand.begin(), cand.end(), dist_lt);
-        cand.erase(std::unique(cand.begin(), cand.end(), dist_eq), cand.end());  // set semantics
+        std::sort(cand.begin(), cand.end(), dist_lt);  // (ids are distinct now: BTreeSet order)
         if (cand_empty()) return HNSW_ERR_EMPTY;
         selected.push_back(cand[cand_head++]);
         while (!cand_empty() && selected.size() < m) {
