@@ -102,6 +102,9 @@ SYMBOLS = {
     "hnsw_upload": (C.c_int, [vp]),
     "hnsw_device_bytes": (C.c_int, [vp, u64p]),
     "hnsw_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
+    "hnsw_get_stat": (C.c_int, [vp, C.c_char_p, u64p]),
+    "hnsw_bench_search_threads": (C.c_int, [vp, f32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, u32p,
+                                            u32p, u64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "hnsw_snapshot_describe": (C.c_int, [vp, C.POINTER(SnapshotDesc)]),
     "hnsw_snapshot_adopt": (C.c_int, [vp, C.POINTER(SnapshotDesc)]),
     "hnsw_snapshot_commit": (C.c_int, [vp]),

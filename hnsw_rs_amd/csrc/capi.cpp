@@ -4,15 +4,22 @@
 
 #include <hip/hip_runtime.h>
 
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <climits>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -36,6 +43,50 @@ struct SearchScratch {
     }
 };
 
+// ---- coalescing of concurrent one-query calls (hnsw_search = the shim's ann_by_vector) ------------------------
+// The reference answers ONE query per call and takes &self, so its callers are many threads each blocked in its
+// own call (template.rs:306-335).  A lone query is a lone wave: 130-190 us on a machine that answers 1024 queries in
+// the same time.  Concurrent calls on one handle are therefore gathered: the first caller to arrive opens a batch and
+// becomes its leader, later callers with the same (n, ef) copy their query into the batch's pinned staging area and
+// sleep on the batch's futex word; the leader launches ONE kernel for everything that arrived, hands every caller
+// its ids and wakes them.  Every query of a batch is answered by its own wave exactly as a lone query would be,
+// so the result of a call does not depend on what it was batched with.
+//   window:  a leader that has seen concurrency (the previous batch held more than one query) waits up to
+//            `window_us` for the callers that were woken together with it to come back; a lone caller never waits.
+//   depth:   at most `depth` batches are on the GPU at once; leaders beyond that keep collecting arrivals.
+struct CoBatch {
+    SearchScratch s;
+    size_t p_q = 0, p_out = 0, r_ids = 0, r_counts = 0, r_stats = 0;  // pinned arena offsets (HostSearchPlan)
+    uint32_t cap = 0, n = 0, ef = 0, dim = 0;
+    std::atomic<uint32_t> count{0};  // queries filed (written under Coalescer::mu, read by the spinning leader)
+    uint32_t wake_at = 0;            // a follower that brings count to this value wakes the leader
+    uint64_t ticket = 0;
+    struct Req {
+        uint32_t *ids, *count;
+    };
+    std::vector<Req> reqs;
+    std::atomic<uint32_t> done{0};     // futex word: 0 = collecting / running, 1 = results handed out
+    std::atomic<uint32_t> readers{0};  // followers that have not picked up their status yet
+    int rc = HNSW_OK;                  // batch-level failure (launch, copy), with its text
+    std::string err;
+    std::vector<int32_t> status;       // per query
+};
+struct Coalescer {
+    std::mutex mu;
+    std::condition_variable cv;  // leaders wait here for their turn
+    std::vector<CoBatch *> open;
+    std::vector<std::unique_ptr<CoBatch>> all;
+    std::vector<CoBatch *> idle;
+    uint64_t next_ticket = 0, serving = 0;
+    uint32_t in_flight = 0, last_size = 1;
+    // options "coalesce_us" (< 0: off, every call launches by itself), "coalesce_depth", "coalesce_max"
+    int64_t window_us = 30;
+    uint32_t depth = 2, cap = 1024;
+    std::atomic<uint64_t> n_batches{0}, n_queries{0}, max_batch{0};
+    // where a leader's time goes, in ns (hnsw_get_stat "coalesce_ns_window" / "_turn" / "_gpu" / "_handout")
+    std::atomic<uint64_t> ns_window{0}, ns_turn{0}, ns_gpu{0}, ns_handout{0};
+};
+
 struct hnsw_index {
     std::unique_ptr<hx::HostIndex> host;
     hx::DeviceIndex dev;
@@ -57,6 +108,9 @@ struct hnsw_index {
     std::mutex mu;
     std::mutex pool_mu;
     std::vector<std::unique_ptr<SearchScratch>> pool;
+    Coalescer co;
+    // counters behind hnsw_get_stat
+    std::atomic<uint64_t> n_uploads{0}, n_point_patches{0}, n_patch_fallbacks{0};
 };
 
 namespace {
@@ -150,6 +204,7 @@ int ensure_uploaded(hnsw_index *h) {
         int rc = h->dev.upload(*h->host, h->device);
         if (rc != HNSW_OK) return rc;
         h->device = h->dev.device;
+        h->n_uploads.fetch_add(1, std::memory_order_relaxed);
     }
     hipError_t e = hipSetDevice(h->dev.device);
     if (e != hipSuccess) {
@@ -244,37 +299,77 @@ struct ScratchLease {  // takes a scratch from the handle's pool, gives it back 
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// host-pointer search with the overflow retry: queries whose visited table filled up are run
-// again with a table twice the size
-int search_host(hnsw_index *h, hx::SearchArgs a_host, const float *Q, uint64_t nq, uint32_t *ids,
-                float *dists, uint32_t *counts, hnsw_query_stats *stats, const uint32_t *entries) {
-    int rc = ensure_uploaded(h);
-    if (rc != HNSW_OK) return rc;
-    const hx::DevView &v = h->dev.view;
-    const uint32_t n = a_host.n, d = v.dim;
-    // device arena: [queries | selection | entries | ids | dists | counts | stats]; the last four are
-    // one contiguous block that comes back in a single copy
-    const size_t o_q = 0, o_sel = o_q + align256(nq * d * 4), o_ent = o_sel + align256(nq * 4),
-                 o_out = o_ent + align256((size_t)(entries ? a_host.n_entry : 0) * 4);
-    const size_t r_ids = 0, r_dists = r_ids + align256(nq * n * 4), r_counts = r_dists + align256(nq * n * 4),
-                 r_stats = r_counts + align256(nq * 4), out_bytes = r_stats + align256(nq * sizeof(hnsw_query_stats));
-    ScratchLease lease(h);
-    if ((rc = lease.prepare(h->dev.device, o_out + out_bytes, out_bytes))) return rc;
-    SearchScratch &s = *lease.s;
-    unsigned char *dv = static_cast<unsigned char *>(s.dev), *hv = static_cast<unsigned char *>(s.pin);
-    HIP_TRY(hipMemcpyAsync(dv + o_q, Q, nq * d * 4, hipMemcpyHostToDevice, s.stream));
-    if ((rc = cosine_queries(h, dv + o_q, nq, s.stream))) return rc;
-    hx::SearchArgs a = a_host;
-    a.Q = reinterpret_cast<const float *>(dv + o_q);
-    a.out_ids = reinterpret_cast<uint32_t *>(dv + o_out + r_ids);
-    a.out_dists = reinterpret_cast<float *>(dv + o_out + r_dists);
-    a.out_counts = reinterpret_cast<uint32_t *>(dv + o_out + r_counts);
-    a.out_stats = reinterpret_cast<hnsw_query_stats *>(dv + o_out + r_stats);
-    if (entries) {
-        HIP_TRY(hipMemcpyAsync(dv + o_ent, entries, (size_t)a.n_entry * 4, hipMemcpyHostToDevice, s.stream));
-        a.entries = reinterpret_cast<const uint32_t *>(dv + o_ent);
+// ---- the host-pointer search path --------------------------------------------------------------------------
+// One search of nq queries in a leased scratch.  Pinned arena: [queries | result block]; device arena:
+// [queries | selection | entries | result block]; the result block is [ids | dists | counts | stats], the same
+// layout on both sides, so it comes back in ONE copy.  The queries reach the device by a true asynchronous
+// copy out of pinned memory (a hipMemcpyAsync out of pageable user memory is staged by the runtime and does
+// not overlap anything).
+struct HostSearchPlan {
+    size_t o_q, o_sel, o_ent, o_out, dev_bytes;           // device arena
+    size_t r_ids, r_dists, r_counts, r_stats, out_bytes;  // result block
+    size_t p_q, p_out, pin_bytes;                         // pinned arena
+};
+HostSearchPlan plan_host_search(uint64_t nq, uint32_t d, uint32_t n, uint32_t n_entry) {
+    HostSearchPlan p{};
+    p.o_q = 0;
+    p.o_sel = p.o_q + align256(nq * d * 4);
+    p.o_ent = p.o_sel + align256(nq * 4);
+    p.o_out = p.o_ent + align256((size_t)n_entry * 4);
+    p.r_ids = 0;
+    p.r_dists = p.r_ids + align256(nq * n * 4);
+    p.r_counts = p.r_dists + align256(nq * n * 4);
+    p.r_stats = p.r_counts + align256(nq * 4);
+    p.out_bytes = p.r_stats + align256(nq * sizeof(hnsw_query_stats));
+    p.dev_bytes = p.o_out + p.out_bytes;
+    p.p_q = 0;
+    p.p_out = align256(nq * d * 4);
+    p.pin_bytes = p.p_out + p.out_bytes;
+    return p;
+}
+
+// text of a per-query failure on the calling thread; returns the status
+int query_status_error(uint64_t i, int32_t status) {
+    switch (status) {
+        case HNSW_OK:
+            break;
+        case HNSW_ERR_NAN_INPUT:
+            set_error("query %llu: NaN in the query or in a distance", (unsigned long long)i);
+            break;
+        case HNSW_ERR_NODE_NOT_IN_GRAPH:
+            set_error("Error in search_layer: node not in Graph (query %llu)", (unsigned long long)i);
+            break;
+        case HNSW_ERR_OVERFLOW:
+            set_error("query %llu: visited table exhausted at its largest size", (unsigned long long)i);
+            break;
+        default:
+            set_error("query %llu failed with status %d", (unsigned long long)i, status);
     }
-    const hnsw_query_stats *st = reinterpret_cast<const hnsw_query_stats *>(hv + r_stats);
+    return status;
+}
+
+// The search itself: the queries are in s.pin + p.p_q (or, for a large call, still in the caller's memory: Q_user),
+// the results are left in s.pin + p.p_out.  Queries whose visited table filled up are run again with a table twice
+// the size.  Returns launch-level errors only; per-query statuses stay in the result block.
+int search_staged(hnsw_index *h, SearchScratch &s, const HostSearchPlan &p, hx::SearchArgs a_host, uint64_t nq,
+                  const uint32_t *entries, const float *Q_user) {
+    const hx::DevView &v = h->dev.view;
+    unsigned char *dv = static_cast<unsigned char *>(s.dev), *hv = static_cast<unsigned char *>(s.pin);
+    int rc;
+    HIP_TRY(hipMemcpyAsync(dv + p.o_q, Q_user ? (const void *)Q_user : (const void *)(hv + p.p_q), nq * v.dim * 4,
+                           hipMemcpyHostToDevice, s.stream));
+    if ((rc = cosine_queries(h, dv + p.o_q, nq, s.stream))) return rc;
+    hx::SearchArgs a = a_host;
+    a.Q = reinterpret_cast<const float *>(dv + p.o_q);
+    a.out_ids = reinterpret_cast<uint32_t *>(dv + p.o_out + p.r_ids);
+    a.out_dists = reinterpret_cast<float *>(dv + p.o_out + p.r_dists);
+    a.out_counts = reinterpret_cast<uint32_t *>(dv + p.o_out + p.r_counts);
+    a.out_stats = reinterpret_cast<hnsw_query_stats *>(dv + p.o_out + p.r_stats);
+    if (entries) {
+        HIP_TRY(hipMemcpyAsync(dv + p.o_ent, entries, (size_t)a.n_entry * 4, hipMemcpyHostToDevice, s.stream));
+        a.entries = reinterpret_cast<const uint32_t *>(dv + p.o_ent);
+    }
+    const hnsw_query_stats *st = reinterpret_cast<const hnsw_query_stats *>(hv + p.p_out + p.r_stats);
     uint32_t ef_max = std::max(a.ef_bottom, a.ef_upper);
     uint32_t slots = hx::default_slots_log2(ef_max, v.S0);
     uint64_t nrun = nq;
@@ -282,45 +377,237 @@ int search_host(hnsw_index *h, hx::SearchArgs a_host, const float *Q, uint64_t n
     while (true) {
         rc = hx::launch_search(v, a, (uint32_t)nrun, slots, s.stream);
         if (rc != HNSW_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(hv, dv + o_out, out_bytes, hipMemcpyDeviceToHost, s.stream));
+        HIP_TRY(hipMemcpyAsync(hv + p.p_out, dv + p.o_out, p.out_bytes, hipMemcpyDeviceToHost, s.stream));
         HIP_TRY(hipStreamSynchronize(s.stream));
         sel.clear();
         for (uint64_t i = 0; i < nq; i++)
             if (st[i].status == HNSW_ERR_OVERFLOW) sel.push_back((uint32_t)i);
         if (sel.empty() || slots >= hx::max_slots_log2(ef_max)) break;
         slots++;
-        HIP_TRY(hipMemcpyAsync(dv + o_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, s.stream));
+        HIP_TRY(hipMemcpyAsync(dv + p.o_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, s.stream));
         HIP_TRY(hipStreamSynchronize(s.stream));  // `sel` is reused by the next round
-        a.qsel = reinterpret_cast<const uint32_t *>(dv + o_sel);
+        a.qsel = reinterpret_cast<const uint32_t *>(dv + p.o_sel);
         nrun = sel.size();
-    }
-    memcpy(ids, hv + r_ids, nq * n * 4);
-    if (dists) memcpy(dists, hv + r_dists, nq * n * 4);
-    if (counts) memcpy(counts, hv + r_counts, nq * 4);
-    if (stats) memcpy(stats, st, nq * sizeof(hnsw_query_stats));
-    for (uint64_t i = 0; i < nq; i++) {
-        if (st[i].status != HNSW_OK) {
-            switch (st[i].status) {
-                case HNSW_ERR_NAN_INPUT:
-                    set_error("query %llu: NaN in the query or in a distance", (unsigned long long)i);
-                    break;
-                case HNSW_ERR_NODE_NOT_IN_GRAPH:
-                    set_error("Error in search_layer: node not in Graph (query %llu)",
-                              (unsigned long long)i);
-                    break;
-                case HNSW_ERR_OVERFLOW:
-                    set_error("query %llu: visited table exhausted at its largest size",
-                              (unsigned long long)i);
-                    break;
-                default:
-                    set_error("query %llu failed with status %d", (unsigned long long)i, st[i].status);
-            }
-            return st[i].status;
-        }
     }
     return HNSW_OK;
 }
 
+// host-pointer search (hnsw_search_batch, hnsw_search_layer): user buffers in, user buffers out
+int search_host(hnsw_index *h, hx::SearchArgs a_host, const float *Q, uint64_t nq, uint32_t *ids,
+                float *dists, uint32_t *counts, hnsw_query_stats *stats, const uint32_t *entries) {
+    int rc = ensure_uploaded(h);
+    if (rc != HNSW_OK) return rc;
+    const hx::DevView &v = h->dev.view;
+    const uint32_t n = a_host.n, d = v.dim;
+    const HostSearchPlan p = plan_host_search(nq, d, n, entries ? a_host.n_entry : 0);
+    // queries go through the pinned arena up to 8 MiB (a batch of 1024 x 100d is 400 KB); beyond that the
+    // runtime's own pageable staging serves, and the pinned arena holds the result block only
+    const bool stage_q = nq * (size_t)d * 4 <= (8u << 20);
+    ScratchLease lease(h);
+    if ((rc = lease.prepare(h->dev.device, p.dev_bytes, stage_q ? p.pin_bytes : p.out_bytes))) return rc;
+    SearchScratch &s = *lease.s;
+    HostSearchPlan pp = p;
+    if (!stage_q) pp.p_out = 0;
+    unsigned char *hv = static_cast<unsigned char *>(s.pin);
+    if (stage_q) memcpy(hv + pp.p_q, Q, nq * (size_t)d * 4);
+    if ((rc = search_staged(h, s, pp, a_host, nq, entries, stage_q ? nullptr : Q))) return rc;
+    const unsigned char *ob = hv + pp.p_out;
+    const hnsw_query_stats *st = reinterpret_cast<const hnsw_query_stats *>(ob + pp.r_stats);
+    memcpy(ids, ob + pp.r_ids, nq * n * 4);
+    if (dists) memcpy(dists, ob + pp.r_dists, nq * n * 4);
+    if (counts) memcpy(counts, ob + pp.r_counts, nq * 4);
+    if (stats) memcpy(stats, st, nq * sizeof(hnsw_query_stats));
+    for (uint64_t i = 0; i < nq; i++)
+        if (st[i].status != HNSW_OK) return query_status_error(i, st[i].status);
+    return HNSW_OK;
+}
+
+
+// ---- hnsw_search through the coalescer ---------------------------------------------------------------------------
+inline void futex_wait(std::atomic<uint32_t> *w, uint32_t while_equals) {
+    while (w->load(std::memory_order_acquire) == while_equals)
+        (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, while_equals, nullptr, nullptr, 0);
+}
+inline void futex_wake_all(std::atomic<uint32_t> *w) {
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
+
+// scratch of a batch sized for `cap` queries of (dim, n); called under Coalescer::mu
+int cobatch_prepare(hnsw_index *h, CoBatch &b, uint32_t cap, uint32_t n, uint32_t ef) {
+    const uint32_t d = h->dev.view.dim;
+    const HostSearchPlan p = plan_host_search(cap, d, n, 0);
+    SearchScratch &s = b.s;
+    if (s.device != h->dev.device) {  // (a handle moved to another device: start over)
+        if (s.dev) (void)hipFree(s.dev);
+        if (s.pin) (void)hipHostFree(s.pin);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+        s.dev = s.pin = nullptr;
+        s.stream = nullptr;
+        s.dev_cap = s.pin_cap = 0;
+        s.device = h->dev.device;
+    }
+    if (!s.stream) HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    if (s.dev_cap < p.dev_bytes) {
+        if (s.dev) (void)hipFree(s.dev);
+        s.dev = nullptr;
+        s.dev_cap = 0;
+        HIP_TRY(hipMalloc(&s.dev, p.dev_bytes));
+        s.dev_cap = p.dev_bytes;
+    }
+    if (s.pin_cap < p.pin_bytes) {
+        if (s.pin) (void)hipHostFree(s.pin);
+        s.pin = nullptr;
+        s.pin_cap = 0;
+        HIP_TRY(hipHostMalloc(&s.pin, p.pin_bytes, hipHostMallocDefault));
+        s.pin_cap = p.pin_bytes;
+    }
+    b.p_q = p.p_q;
+    b.p_out = p.p_out;
+    b.r_ids = p.r_ids;
+    b.r_counts = p.r_counts;
+    b.r_stats = p.r_stats;
+    b.cap = cap;
+    b.n = n;
+    b.ef = ef;
+    b.dim = d;
+    b.count.store(0, std::memory_order_relaxed);
+    b.wake_at = 0;
+    b.done.store(0, std::memory_order_relaxed);
+    b.readers.store(0, std::memory_order_relaxed);
+    b.rc = HNSW_OK;
+    b.err.clear();
+    if (b.reqs.size() < cap) b.reqs.resize(cap);
+    if (b.status.size() < cap) b.status.resize(cap);
+    return HNSW_OK;
+}
+
+int search_coalesced(hnsw_index *h, const float *q, uint32_t n, uint32_t ef, uint32_t *ids, uint32_t *count) {
+    int rc = ensure_uploaded(h);
+    if (rc != HNSW_OK) return rc;
+    Coalescer &co = h->co;
+    const uint32_t d = h->dev.view.dim;
+    std::unique_lock<std::mutex> lk(co.mu);
+    CoBatch *b = nullptr;
+    for (CoBatch *o : co.open)
+        if (o->n == n && o->ef == ef && o->dim == d && o->count.load(std::memory_order_relaxed) < o->cap) {
+            b = o;
+            break;
+        }
+    const bool leader = b == nullptr;
+    if (leader) {
+        if (!co.idle.empty()) {
+            b = co.idle.back();
+            co.idle.pop_back();
+        } else {
+            co.all.emplace_back(new CoBatch());
+            b = co.all.back().get();
+        }
+        if ((rc = cobatch_prepare(h, *b, co.cap, n, ef)) != HNSW_OK) {
+            co.idle.push_back(b);
+            return rc;
+        }
+        b->ticket = co.next_ticket++;
+        co.open.push_back(b);
+    }
+    const uint32_t slot = b->count.load(std::memory_order_relaxed);
+    memcpy(static_cast<unsigned char *>(b->s.pin) + b->p_q + (size_t)slot * d * 4, q, (size_t)d * 4);
+    b->reqs[slot] = CoBatch::Req{ids, count};
+    b->count.store(slot + 1, std::memory_order_release);
+
+    if (!leader) {
+        if (slot + 1 == b->wake_at) co.cv.notify_all();
+        lk.unlock();
+        futex_wait(&b->done, 0);
+        int my = b->rc;
+        if (my != HNSW_OK)
+            set_error("%s", b->err.c_str());
+        else
+            my = query_status_error(0, b->status[slot]);
+        if (b->readers.fetch_sub(1, std::memory_order_acq_rel) == 1) {  // the last one out returns the batch
+            std::lock_guard<std::mutex> g(co.mu);
+            co.idle.push_back(b);
+        }
+        return my;
+    }
+
+    // ---- leader ----
+    using sclk = std::chrono::steady_clock;
+    auto ns_since = [](sclk::time_point t) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(sclk::now() - t).count(); };
+    const auto t_lead = sclk::now();
+    if (co.window_us > 0 && co.last_size > 1) {
+        // callers woken together come back together: wait for as many as the previous batch held, at most the
+        // window (spinning: a timed sleep of tens of microseconds wakes up 50 us late)
+        const uint32_t target = std::min(co.last_size, b->cap);
+        lk.unlock();
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(co.window_us);
+        while (b->count.load(std::memory_order_acquire) < target && std::chrono::steady_clock::now() < deadline) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        lk.lock();
+    }
+    b->wake_at = b->cap;  // while waiting for a turn, only a full batch is worth a wake-up
+    co.ns_window.fetch_add(ns_since(t_lead), std::memory_order_relaxed);
+    const auto t_turn = sclk::now();
+    while (!(co.serving == b->ticket && co.in_flight < co.depth)) co.cv.wait(lk);
+    co.ns_turn.fetch_add(ns_since(t_turn), std::memory_order_relaxed);
+    co.open.erase(std::find(co.open.begin(), co.open.end(), b));
+    co.serving++;
+    co.in_flight++;
+    const uint32_t nq = b->count.load(std::memory_order_relaxed);
+    co.last_size = nq;
+    co.cv.notify_all();  // the next ticket may be waiting for `serving`
+    lk.unlock();
+
+    co.n_batches.fetch_add(1, std::memory_order_relaxed);
+    co.n_queries.fetch_add(nq, std::memory_order_relaxed);
+    uint64_t mb = co.max_batch.load(std::memory_order_relaxed);
+    while (nq > mb && !co.max_batch.compare_exchange_weak(mb, nq)) {
+    }
+    HostSearchPlan p = plan_host_search(nq, d, n, 0);  // the device arena and the result block are laid out for nq
+    p.p_q = b->p_q;
+    p.p_out = b->p_out;  // (the pinned result block starts where the batch's capacity put it)
+    hx::DevView dummy{};
+    dummy.nb_layers = h->dev.view.nb_layers;
+    hx::SearchArgs a = ann_args(dummy, nullptr, n, ef, nullptr, nullptr, nullptr, nullptr);
+    const auto t_gpu = sclk::now();
+    rc = search_staged(h, b->s, p, a, nq, nullptr, nullptr);
+    co.ns_gpu.fetch_add(ns_since(t_gpu), std::memory_order_relaxed);
+    const auto t_hand = sclk::now();
+    {
+        std::lock_guard<std::mutex> g(co.mu);
+        co.in_flight--;
+    }
+    co.cv.notify_all();
+    int my;
+    if (rc != HNSW_OK) {
+        b->rc = rc;
+        b->err = hx::get_error();
+        my = rc;
+    } else {
+        const unsigned char *ob = static_cast<const unsigned char *>(b->s.pin) + p.p_out;
+        const uint32_t *o_ids = reinterpret_cast<const uint32_t *>(ob + p.r_ids);
+        const uint32_t *o_cnt = reinterpret_cast<const uint32_t *>(ob + p.r_counts);
+        const hnsw_query_stats *st = reinterpret_cast<const hnsw_query_stats *>(ob + p.r_stats);
+        for (uint32_t i = 0; i < nq; i++) {
+            memcpy(b->reqs[i].ids, o_ids + (size_t)i * n, (size_t)n * 4);
+            if (b->reqs[i].count) *b->reqs[i].count = o_cnt[i];
+            b->status[i] = st[i].status;
+        }
+        my = query_status_error(0, b->status[slot]);
+    }
+    if (nq > 1) {
+        b->readers.store(nq - 1, std::memory_order_release);
+        b->done.store(1, std::memory_order_release);
+        futex_wake_all(&b->done);
+    } else {
+        std::lock_guard<std::mutex> g(co.mu);
+        co.idle.push_back(b);
+    }
+    co.ns_handout.fetch_add(ns_since(t_hand), std::memory_order_relaxed);
+    return my;
+}
 
 // ---------------------------------------------------------------------------------------------
 // On-device index build: batch-synchronous insert_bulk.
@@ -1160,7 +1447,28 @@ int hnsw_insert_vec_level(hnsw_index *h, const float *v, int level, uint32_t *ou
     if (h->incomplete_build) return check_search_args(h, 1);
     std::vector<float> unit;
     v = cosine_rows(h, v, 1, unit);
-    return h->host->insert_vec(v, level, out_id);
+    // The reference's callers search right after an insert_vec (eval_glove/src/main.rs:37-41).  When the HBM snapshot
+    // was current before the insertion it is patched -- the new row and the adjacency rows the insertion touched --
+    // instead of being thrown away and uploaded again by the next search (DeviceIndex::append_point).
+    std::lock_guard<std::mutex> g(h->mu);
+    const bool live = h->dev.valid && h->dev.current(*h->host) &&
+                      !(getenv("HNSW_MI355X_REUPLOAD") && atoi(getenv("HNSW_MI355X_REUPLOAD")) != 0);
+    std::vector<uint64_t> touched;
+    uint32_t id = 0;
+    int rc;
+    {
+        hx::DirtyScope scope(live ? &touched : nullptr);
+        rc = h->host->insert_vec(v, level, &id);
+    }
+    if (rc != HNSW_OK) return rc;
+    if (out_id) *out_id = id;
+    if (live) {
+        if (h->dev.append_point(*h->host, id, touched))
+            h->n_point_patches.fetch_add(1, std::memory_order_relaxed);
+        else
+            h->n_patch_fallbacks.fetch_add(1, std::memory_order_relaxed);
+    }
+    return HNSW_OK;
 }
 int hnsw_import_points(hnsw_index *h, const float *rows, uint64_t n, const uint8_t *levels) {
     if (!h || !rows) return HNSW_ERR_ARG;
@@ -1179,6 +1487,13 @@ int hnsw_import_layer(hnsw_index *h, uint32_t layer, uint64_t n_nodes, const uin
 // ---- query -------------------------------------------------------------------------------------
 int hnsw_search(hnsw_index *h, const float *q, uint32_t n, uint32_t ef, uint32_t *ids,
                 uint32_t *count) {
+    // concurrent callers are gathered into one launch (the coalescer above); ef beyond the register-resident list
+    // (the HBM-spill kernel) and result lists of thousands of ids go by themselves
+    if (h && q && ids && n > 0 && n <= 1024 && ef <= 1024 && h->co.window_us >= 0) {
+        const int rc = check_search_args(h, ef);
+        if (rc != HNSW_OK) return rc;
+        return search_coalesced(h, q, n, ef, ids, count);
+    }
     return hnsw_search_batch(h, q, 1, n, ef, ids, nullptr, count, nullptr);
 }
 
@@ -1677,6 +1992,19 @@ int hnsw_set_option(hnsw_index *h, const char *key, int64_t value) {
         }
         h->build_batch_div = (uint32_t)std::min<int64_t>(value, 1 << 20);
         return HNSW_OK;
+    } else if (!strcmp(key, "coalesce_us") || !strcmp(key, "coalesce_depth") || !strcmp(key, "coalesce_max")) {
+        std::lock_guard<std::mutex> cg(h->co.mu);
+        if (!strcmp(key, "coalesce_us")) {
+            h->co.window_us = std::min<int64_t>(value, 100000);
+        } else if (value < 1) {
+            set_error("%s must be positive", key);
+            return HNSW_ERR_ARG;
+        } else if (!strcmp(key, "coalesce_depth")) {
+            h->co.depth = (uint32_t)std::min<int64_t>(value, 64);
+        } else {
+            h->co.cap = (uint32_t)std::min<int64_t>(value, 65536);
+        }
+        return HNSW_OK;
     } else {
         set_error("unknown option %s", key);
         return HNSW_ERR_ARG;
@@ -1687,6 +2015,34 @@ int hnsw_set_option(hnsw_index *h, const char *key, int64_t value) {
 int hnsw_device_bytes(const hnsw_index *h, uint64_t *bytes) {
     if (!h || !bytes) return HNSW_ERR_ARG;
     *bytes = h->dev.valid ? h->dev.bytes : 0;
+    return HNSW_OK;
+}
+int hnsw_get_stat(const hnsw_index *h, const char *key, uint64_t *out) {
+    if (!h || !key || !out) return HNSW_ERR_ARG;
+    if (!strcmp(key, "uploads")) {
+        *out = h->n_uploads.load();
+    } else if (!strcmp(key, "point_patches")) {
+        *out = h->n_point_patches.load();
+    } else if (!strcmp(key, "patch_fallbacks")) {
+        *out = h->n_patch_fallbacks.load();
+    } else if (!strcmp(key, "coalesced_batches")) {
+        *out = h->co.n_batches.load();
+    } else if (!strcmp(key, "coalesced_queries")) {
+        *out = h->co.n_queries.load();
+    } else if (!strcmp(key, "coalesced_max_batch")) {
+        *out = h->co.max_batch.load();
+    } else if (!strcmp(key, "coalesce_ns_window")) {
+        *out = h->co.ns_window.load();
+    } else if (!strcmp(key, "coalesce_ns_turn")) {
+        *out = h->co.ns_turn.load();
+    } else if (!strcmp(key, "coalesce_ns_gpu")) {
+        *out = h->co.ns_gpu.load();
+    } else if (!strcmp(key, "coalesce_ns_handout")) {
+        *out = h->co.ns_handout.load();
+    } else {
+        set_error("unknown statistic %s", key);
+        return HNSW_ERR_ARG;
+    }
     return HNSW_OK;
 }
 
@@ -1813,6 +2169,84 @@ int hnsw_synth_rows(int recipe, uint64_t seed, uint64_t first_row, uint64_t n, u
                     uint32_t nb_threads) {
     if (!out) return HNSW_ERR_ARG;
     return hx::synth_rows(recipe, seed, first_row, n, d, out, nb_threads);
+}
+// T host threads, each blocked in its own hnsw_search call like the reference's callers (ann_by_vector(&self), one
+// query per call): thread t answers queries t, t + T, t + 2T, ... of Q, again and again until `seconds` have passed
+// and every query has been answered at least once.  ids receives each query's LAST answer (so the caller can hold
+// the run to the oracle), lat_us = {p50, p90, p99, max, mean} of the per-call latencies.
+int hnsw_bench_search_threads(hnsw_index *h, const float *Q, uint64_t nq, uint32_t n, uint32_t ef, uint32_t threads,
+                              double seconds, uint32_t *ids, uint32_t *counts, uint64_t *calls_out, double *wall_s,
+                              double *lat_us) {
+    if (!h || !Q || !ids || nq == 0 || n == 0 || threads == 0 || threads > 4096) return HNSW_ERR_ARG;
+    int rc = check_search_args(h, ef);
+    if (rc != HNSW_OK) return rc;
+    if ((rc = ensure_uploaded(h))) return rc;
+    const uint32_t d = h->dev.view.dim;
+    const uint32_t T = (uint32_t)std::min<uint64_t>(threads, nq);
+    std::vector<std::vector<float>> lat(T);
+    std::atomic<int> first_rc{HNSW_OK};
+    std::string first_msg;
+    std::mutex msg_mu;
+    std::atomic<uint32_t> ready{0};
+    std::atomic<bool> go{false};
+    using clk = std::chrono::steady_clock;
+    clk::time_point t_start;
+    auto work = [&](uint32_t t) {
+        std::vector<float> &L = lat[t];
+        L.reserve(1 << 16);
+        ready.fetch_add(1);
+        while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+        const auto deadline = t_start + std::chrono::duration_cast<clk::duration>(std::chrono::duration<double>(seconds));
+        bool full_pass = false;
+        while (first_rc.load(std::memory_order_relaxed) == HNSW_OK) {
+            for (uint64_t i = t; i < nq; i += T) {
+                uint32_t cnt = 0;
+                const auto a = clk::now();
+                const int r = hnsw_search(h, Q + i * d, n, ef, ids + i * n, &cnt);
+                const auto b = clk::now();
+                if (counts) counts[i] = cnt;
+                if (r != HNSW_OK) {
+                    std::lock_guard<std::mutex> g(msg_mu);
+                    if (first_rc.load() == HNSW_OK) {
+                        first_msg = hx::get_error();
+                        first_rc.store(r);
+                    }
+                    return;
+                }
+                L.push_back(std::chrono::duration<float, std::micro>(b - a).count());
+                if (full_pass && b >= deadline) return;
+            }
+            full_pass = true;
+            if (clk::now() >= deadline) return;
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < T; t++) th.emplace_back(work, t);
+    while (ready.load() < T) std::this_thread::yield();
+    t_start = clk::now();
+    go.store(true, std::memory_order_release);
+    for (auto &t : th) t.join();
+    const double wall = std::chrono::duration<double>(clk::now() - t_start).count();
+    if (first_rc.load() != HNSW_OK) {
+        set_error("%s", first_msg.c_str());
+        return first_rc.load();
+    }
+    std::vector<float> all;
+    for (auto &L : lat) all.insert(all.end(), L.begin(), L.end());
+    std::sort(all.begin(), all.end());
+    if (calls_out) *calls_out = all.size();
+    if (wall_s) *wall_s = wall;
+    if (lat_us && !all.empty()) {
+        auto pct = [&](double p) { return (double)all[std::min(all.size() - 1, (size_t)(p * all.size()))]; };
+        double sum = 0;
+        for (float x : all) sum += x;
+        lat_us[0] = pct(0.50);
+        lat_us[1] = pct(0.90);
+        lat_us[2] = pct(0.99);
+        lat_us[3] = all.back();
+        lat_us[4] = sum / all.size();
+    }
+    return HNSW_OK;
 }
 int hnsw_draw_levels(uint32_t m, uint64_t n, uint8_t *out) {
     if (!out || m < 2) return HNSW_ERR_ARG;

@@ -43,12 +43,20 @@ void DeviceIndex::release() {
             if (b) (void)hipFree(b);
             b = nullptr;
         }
+        if (pin_) (void)hipHostFree(pin_);
+        if (stage_) (void)hipFree(stage_);
+        if (pstream_) (void)hipStreamDestroy(pstream_);
+        pin_ = stage_ = nullptr;
+        pstream_ = nullptr;
+        pin_cap_ = stage_cap_ = 0;
         if (cur >= 0) (void)hipSetDevice(cur);
     }
     valid = false;
     replica = false;
     bytes = 0;
+    n_ovf_nbrs_ = 0;
     for (uint64_t &z : sizes_) z = 0;
+    for (uint64_t &z : caps_) z = 0;
 }
 
 void DeviceIndex::describe(uint64_t (&nbytes)[7], void *(&ptrs)[7]) const {
@@ -73,7 +81,7 @@ int DeviceIndex::adopt_alloc(int dev, const uint64_t (&nbytes)[7], void *(&ptrs)
         ptrs[i] = nullptr;
         if (nbytes[i] == 0) continue;
         HIP_TRY(hipMalloc(&bufs_[i], nbytes[i]));
-        sizes_[i] = nbytes[i];
+        sizes_[i] = caps_[i] = nbytes[i];
         ptrs[i] = bufs_[i];
         bytes += nbytes[i];
     }
@@ -188,12 +196,187 @@ bool DeviceIndex::refresh_rows(const HostIndex &idx, const std::vector<uint64_t>
         bytes += ovf_off.size() * 4 + ovf_nbrs.size() * 4 - sizes_[4] - sizes_[5];
         bufs_[4] = off;
         bufs_[5] = nb;
-        sizes_[4] = ovf_off.size() * 4;
-        sizes_[5] = ovf_nbrs.size() * 4;
+        sizes_[4] = caps_[4] = ovf_off.size() * 4;
+        sizes_[5] = caps_[5] = ovf_nbrs.size() * 4;
+        n_ovf_nbrs_ = ovf_nbrs.size();
         view.ovf_off = (const uint32_t *)off;
         view.ovf_nbrs = (const uint32_t *)nb;
     }
     view.ep = idx.params.ep;
+    version_seen = idx.version;
+    return true;
+}
+
+// array i to at least need_bytes, keeping its contents; what is added is filled with fill_byte (0xFF = empty
+// adjacency slots / "no upper rows"), so that rows handed out later start empty
+bool DeviceIndex::grow(int i, uint64_t need_bytes, int fill_byte) {
+    if (need_bytes <= caps_[i]) return true;
+    const uint64_t cap = std::max<uint64_t>(need_bytes, caps_[i] + caps_[i] / 8 + 4096);
+    void *nb = nullptr;
+    if (hipMalloc(&nb, cap) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    // on the patch stream, and finished before the old array goes (a memset on the null stream would not be
+    // ordered against the patch kernel that follows on pstream_)
+    bool ok = true;
+    if (bufs_[i] && sizes_[i]) ok = hipMemcpyAsync(nb, bufs_[i], sizes_[i], hipMemcpyDeviceToDevice, pstream_) == hipSuccess;
+    ok = ok && hipMemsetAsync(static_cast<unsigned char *>(nb) + sizes_[i], fill_byte, cap - sizes_[i], pstream_) == hipSuccess;
+    ok = ok && hipStreamSynchronize(pstream_) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        (void)hipFree(nb);
+        return false;
+    }
+    if (bufs_[i]) (void)hipFree(bufs_[i]);
+    bytes += cap - caps_[i];
+    bufs_[i] = nb;
+    caps_[i] = cap;
+    return true;
+}
+
+bool DeviceIndex::append_point(const HostIndex &idx, NodeID id, const std::vector<uint64_t> &layer_row) {
+    const uint64_t N = idx.len();
+    if (!valid || replica || N == 0 || id != N - 1 || view.n_points + 1 != N || idx.kind != view.kind ||
+        idx.dim != view.dim || idx.nb_layers() < view.nb_layers)
+        return false;
+    if (view.S0 != adj_stride(idx.layer_m(0), 32) || view.S1 != adj_stride(idx.params.m, 8)) return false;
+    if (hipSetDevice(device) != hipSuccess) return false;
+    const bool q8 = idx.kind == HNSW_VEC_QUANT8, fat = view.fat_stride != 0 && bufs_[6];
+    const uint32_t S0 = view.S0, S1 = view.S1;
+
+    // ---- what is written, as (array, byte offset, words) over one staging buffer ----
+    struct Piece {
+        int array;
+        uint64_t offset;
+        uint32_t src_word, n_words;
+    };
+    std::vector<Piece> pieces;
+    std::vector<uint32_t> st;  // the staging words
+    auto add = [&](int array, uint64_t offset, uint32_t n_words) -> uint32_t * {
+        pieces.push_back(Piece{array, offset, (uint32_t)st.size(), n_words});
+        st.resize(st.size() + n_words, 0);
+        return &st[st.size() - n_words];
+    };
+    {  // the vector row, in the layout of upload()
+        uint8_t *o = reinterpret_cast<uint8_t *>(add(0, (uint64_t)id * view.row_stride, view.row_stride / 4));
+        if (q8) {
+            const uint32_t d = idx.dim, nch = d / 8, rem = d % 8, half = view.half_bytes;
+            const uint8_t *c = &idx.codes[(size_t)id * d];
+            for (uint32_t h = 0; h < 2; h++) {
+                uint8_t *oh = o + h * half;
+                memcpy(oh, &idx.mins[id], 4);
+                memcpy(oh + 4, &idx.deltas[id], 4);
+                for (uint32_t ch = 0; ch < nch; ch++) memcpy(oh + 8 + 4 * ch, c + 8 * ch + 4 * h, 4);
+                if (h == 0) memcpy(oh + 8 + 4 * nch, c + 8 * nch, rem);
+            }
+        } else {
+            memcpy(o, &idx.vals[(size_t)id * idx.dim], 4 * (size_t)idx.dim);
+        }
+    }
+    *add(3, (uint64_t)id * 4, 1) = idx.upper_base[id];
+    // the touched adjacency rows and the new point's own (a row without edges stays empty, but it must exist)
+    std::vector<std::pair<uint64_t, uint32_t>> rows;  // (row index, 0 = adj0 / 1 = adj_up)
+    for (uint64_t key : layer_row) {
+        const uint32_t layer = (uint32_t)(key >> 32);
+        const NodeID node = (NodeID)key;
+        if (!idx.in_layer(layer, node)) return false;
+        rows.push_back(layer == 0 ? std::make_pair((uint64_t)node, 0u)
+                                  : std::make_pair((uint64_t)idx.upper_base[node] + layer - 1, 1u));
+    }
+    for (uint32_t l = 0; l <= idx.levels[id]; l++)
+        rows.push_back(l == 0 ? std::make_pair((uint64_t)id, 0u) : std::make_pair((uint64_t)idx.upper_base[id] + l - 1, 1u));
+    std::sort(rows.begin(), rows.end(), [](const auto &x, const auto &y) {
+        return x.second != y.second ? x.second < y.second : x.first < y.first;
+    });
+    rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+    uint64_t n_ovf_rows = sizes_[4] / 4 - 1, n_ovf_nbrs = n_ovf_nbrs_;
+    std::vector<NodeID> tmp;
+    std::vector<uint32_t> fat_nodes;
+    for (const auto &r : rows) {
+        const bool up = r.second != 0;
+        const uint32_t S = up ? S1 : S0;
+        const std::vector<NodeID> &src = up ? idx.adj_up[r.first] : idx.adj0[r.first];
+        uint32_t *slots = add(up ? 2 : 1, r.first * S * 4ull, S);
+        if (pack_adj_row(src, slots, S, tmp)) {  // more ids than slots: the rest goes to a NEW overflow list
+            slots[S - 1] = HX_OVF_FLAG | (uint32_t)n_ovf_rows;
+            const uint32_t extra = (uint32_t)(tmp.size() - (S - 1));
+            uint32_t *nb = add(5, n_ovf_nbrs * 4, extra);  // (`slots` is stale from here on: st may have moved)
+            std::copy(tmp.begin() + (S - 1), tmp.end(), nb);
+            n_ovf_nbrs += extra;
+            n_ovf_rows++;
+            *add(4, n_ovf_rows * 4, 1) = (uint32_t)n_ovf_nbrs;
+        }
+        if (!up) fat_nodes.push_back((uint32_t)r.first);
+    }
+    const uint32_t n_fat = fat ? (uint32_t)fat_nodes.size() : 0;
+    const uint32_t fat_word = (uint32_t)st.size();
+    if (n_fat) st.insert(st.end(), fat_nodes.begin(), fat_nodes.end());
+
+    // ---- room in the arrays ----
+    const uint64_t need[7] = {N * view.row_stride,
+                              N * S0 * 4ull,
+                              std::max<uint64_t>(1, idx.adj_up.size()) * S1 * 4ull,
+                              N * 4ull,
+                              (n_ovf_rows + 1) * 4ull,
+                              std::max<uint64_t>(1, n_ovf_nbrs) * 4ull,
+                              fat ? N * view.fat_stride : 0};
+    const int fill[7] = {0, 0xFF, 0xFF, 0xFF, 0, 0xFF, 0};
+    if (!pstream_ && hipStreamCreateWithFlags(&pstream_, hipStreamNonBlocking) != hipSuccess) return false;
+    for (int i = 0; i < 7; i++)
+        if (need[i] && !grow(i, need[i], fill[i])) return false;  // (nothing written yet: the snapshot is merely stale)
+
+    // ---- staging: [descriptors | words] through one pinned buffer and one copy ----
+    const size_t desc_bytes = (pieces.size() * sizeof(PatchDesc) + 255) & ~(size_t)255;
+    const size_t total = desc_bytes + st.size() * 4;
+    if (pin_cap_ < total) {
+        if (pin_) (void)hipHostFree(pin_);
+        if (stage_) (void)hipFree(stage_);
+        pin_ = stage_ = nullptr;
+        pin_cap_ = stage_cap_ = 0;
+        const size_t cap = std::max<size_t>(2 * total, 64 << 10);
+        if (hipHostMalloc(&pin_, cap, hipHostMallocDefault) != hipSuccess || hipMalloc(&stage_, cap) != hipSuccess) {
+            (void)hipGetLastError();
+            if (pin_) (void)hipHostFree(pin_);
+            if (stage_) (void)hipFree(stage_);
+            pin_ = stage_ = nullptr;
+            return false;
+        }
+        pin_cap_ = stage_cap_ = cap;
+    }
+    PatchDesc *pd = static_cast<PatchDesc *>(pin_);
+    for (size_t i = 0; i < pieces.size(); i++) {
+        const Piece &pc = pieces[i];
+        pd[i].dst = static_cast<unsigned char *>(bufs_[pc.array]) + pc.offset;
+        pd[i].src_word = pc.src_word;
+        pd[i].n_words = pc.n_words;
+    }
+    memcpy(static_cast<unsigned char *>(pin_) + desc_bytes, st.data(), st.size() * 4);
+    const uint32_t *d_words = reinterpret_cast<const uint32_t *>(static_cast<unsigned char *>(stage_) + desc_bytes);
+    DevView v = view;
+    v.rows = (const uint8_t *)bufs_[0];
+    v.adj0 = (const uint32_t *)bufs_[1];
+    v.adj_up = (const uint32_t *)bufs_[2];
+    v.upper_base = (const uint32_t *)bufs_[3];
+    v.ovf_off = (const uint32_t *)bufs_[4];
+    v.ovf_nbrs = (const uint32_t *)bufs_[5];
+    v.fat = (const uint8_t *)bufs_[6];
+    v.n_points = (uint32_t)N;
+    v.nb_layers = idx.nb_layers();
+    v.ep = idx.params.ep;
+    bool ok = hipMemcpyAsync(stage_, pin_, total, hipMemcpyHostToDevice, pstream_) == hipSuccess &&
+              launch_patch(static_cast<const PatchDesc *>(stage_), d_words, (uint32_t)pieces.size(), pstream_) == HNSW_OK &&
+              (!n_fat || launch_fat_rebuild(v, static_cast<uint8_t *>(bufs_[6]), d_words + fat_word, n_fat, pstream_) == HNSW_OK) &&
+              hipStreamSynchronize(pstream_) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        valid = false;  // half-written: the next search uploads
+        return false;
+    }
+    for (int i = 0; i < 7; i++)
+        if (need[i]) sizes_[i] = need[i];
+    n_ovf_nbrs_ = n_ovf_nbrs;
+    view = v;
     version_seen = idx.version;
     return true;
 }
@@ -389,7 +572,7 @@ int DeviceIndex::upload(const HostIndex &idx, int dev) {
     bytes = 0;
     auto dev_alloc = [&](int i, size_t nbytes) -> int {
         HIP_TRY(hipMalloc(&bufs_[i], nbytes));
-        sizes_[i] = nbytes;
+        sizes_[i] = caps_[i] = nbytes;
         bytes += nbytes;
         return HNSW_OK;
     };
@@ -450,6 +633,7 @@ int DeviceIndex::upload(const HostIndex &idx, int dev) {
             if (pack_adj_row(idx.adj_up[r], &adj_up[r * v.S1], v.S1, tmp))
                 adj_up[r * v.S1 + (v.S1 - 1)] = overflow_slot(idx.adj_up[r], v.S1);
     }
+    n_ovf_nbrs_ = ovf_nbrs.size();
     if (ovf_nbrs.empty()) ovf_nbrs.push_back(HX_EMPTY_SLOT);
     std::vector<uint32_t> ub(idx.upper_base.begin(), idx.upper_base.end());
     ub.resize(N, UINT32_MAX);
@@ -494,7 +678,7 @@ int DeviceIndex::upload(const HostIndex &idx, int dev) {
             HIP_TRY(hipMalloc(&bufs_[i], ups[i].nbytes));
         }
         HIP_TRY(hipMemcpy(bufs_[i], ups[i].src, ups[i].nbytes, hipMemcpyHostToDevice));
-        sizes_[i] = ups[i].nbytes;
+        sizes_[i] = caps_[i] = ups[i].nbytes;
         bytes += ups[i].nbytes;
     }
     v.rows = (const uint8_t *)bufs_[0];

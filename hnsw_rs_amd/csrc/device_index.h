@@ -128,6 +128,15 @@ int sort_edge_pairs(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint
 int sort_edge_keys(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out, uint32_t n,
                    uint32_t nb_layers, hipStream_t stream);
 
+// one piece of a snapshot patch (patch.hip): n_words 32-bit words of the staging buffer, from word src_word on,
+// are written to dst
+struct PatchDesc {
+    void *dst;
+    uint32_t src_word, n_words;
+};
+int launch_patch(const PatchDesc *d_desc, const uint32_t *d_staging, uint32_t n, hipStream_t stream);
+int launch_fat_rebuild(const DevView &v, uint8_t *fat, const uint32_t *d_nodes, uint32_t n, hipStream_t stream);
+
 class DeviceIndex {
   public:
     ~DeviceIndex() { release(); }
@@ -143,6 +152,15 @@ class DeviceIndex {
     // (snapshot left as it was, the next search uploads) when that is not possible: inline rows wanted, or
     // overflow lists already present.  layer_row: (layer << 32) | node id.
     bool refresh_rows(const HostIndex &idx, const std::vector<uint64_t> &layer_row);
+    // HNSW::insert_vec on a live snapshot (template.rs:165-173; its callers search right after it,
+    // eval_glove/src/main.rs:37-41): point `id` = the last one of idx has just been stored and connected on the host
+    // and layer_row lists the adjacency rows that insertion touched.  The new vector row, its upper_base word and
+    // the touched rows (with their overflow lists, and the inline-rows blocks where that copy exists) are packed
+    // into one staging buffer and written by one kernel (patch.hip); the arrays have room for the next points or
+    // are grown by a device-to-device copy (capacity + 1/8), so an insertion costs O(rows touched), not O(N).
+    // Returns false -- snapshot left stale, the next search uploads -- when the snapshot is not the state before
+    // this insertion or a HIP call fails.
+    bool append_point(const HostIndex &idx, NodeID id, const std::vector<uint64_t> &layer_row);
     // The adjacency array of layer 0 (which = 0) or of the upper layers (1) back to the host, in pieces through two
     // pinned buffers: consume(row_lo, row_hi, slots) sees rows [row_lo, row_hi) of S slots each while the next piece is
     // on the wire (the read-back at the end of an on-device build: 12.8 GB at 100M points).
@@ -169,7 +187,14 @@ class DeviceIndex {
 
   private:
     void *bufs_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    uint64_t sizes_[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint64_t sizes_[7] = {0, 0, 0, 0, 0, 0, 0};  // bytes in use (what a replica receives)
+    uint64_t caps_[7] = {0, 0, 0, 0, 0, 0, 0};   // bytes allocated (append_point leaves room behind the arrays)
+    uint64_t n_ovf_nbrs_ = 0;                    // ids in the overflow lists (array 5 holds one dummy word when none)
+    bool grow(int i, uint64_t need_bytes, int fill_byte);
+    // staging of append_point: one pinned buffer, one device buffer, one stream
+    void *pin_ = nullptr, *stage_ = nullptr;
+    size_t pin_cap_ = 0, stage_cap_ = 0;
+    hipStream_t pstream_ = nullptr;
 };
 
 // row packing helpers shared by upload and tests

@@ -868,16 +868,18 @@ int HostIndex::insert_bulk(const float *rows, uint64_t n, uint32_t nb_threads, b
     return HNSW_OK;
 }
 
-// HNSW::insert_vec, template.rs:165-173
+// HNSW::insert_vec, template.rs:165-173.  The reference makes a fresh Inserter per call (template.rs:171); its
+// state is cleared at the start of every insertion (inserter.rs:53-68), so ONE kept on the index behaves the same
+// and an insertion does not pay an O(N) allocation of visited stamps (nor a new lock array: nothing else may
+// touch the index during an insert_vec, the rows' locks are only for insert_bulk's threads).
 int HostIndex::insert_vec(const float *v, int level, NodeID *out_id) {
     std::vector<NodeID> ids;
     uint8_t lv = (uint8_t)level;
     int rc = store_points(v, 1, level < 0 ? nullptr : &lv, &ids);
     if (rc != HNSW_OK) return rc;
-    ensure_locks();
-    Inserter ins;  // Inserter::new(), template.rs:171
-    ins.vstamp.assign(len(), 0);
-    rc = insert(ids[0], ins);
+    if (!single_ins_) single_ins_.reset(new_inserter(0), free_inserter);
+    single_ins_->clear_all();  // a fresh Inserter holds no results (they would be re-applied if the point is the new entry point, inserter.rs:42-45)
+    rc = insert(ids[0], *single_ins_);
     version++;
     if (rc != HNSW_OK) return rc;
     if (out_id) *out_id = ids[0];

@@ -156,6 +156,7 @@ class HostIndex {
     void ensure_locks();
     mutable std::unique_ptr<std::atomic<uint8_t>[]> lock0_, lock_up_;
     mutable size_t lock0_n_ = 0, lock_up_n_ = 0;
+    std::shared_ptr<Inserter> single_ins_;  // insert_vec's Inserter (never shared between indexes: see the copy constructor)
 };
 
 // opaque Inserter handles for code outside host_index.cpp

@@ -374,6 +374,29 @@ class HNSW:
         check(self._L.hnsw_device_bytes(self._h, C.byref(b)))
         return b.value
 
+    def stat(self, key):
+        """hnsw_get_stat: "uploads", "point_patches", "patch_fallbacks", "coalesced_batches", "coalesced_queries",
+        "coalesced_max_batch" """
+        b = C.c_uint64()
+        check(self._L.hnsw_get_stat(self._h, key.encode(), C.byref(b)))
+        return b.value
+
+    def search_threads(self, Q, n, ef, threads, seconds):
+        """The reference's call pattern as a load (hnsw_bench_search_threads): `threads` host threads, each blocked in
+        its own one-query hnsw_search call.  -> (ids [nq, n], counts [nq], calls, wall seconds,
+        {p50, p90, p99, max, mean} latency in us)"""
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        if Q.ndim != 2 or Q.shape[1] != self.dim:
+            raise HnswError(_lib.ERR_BAD_DIM, "queries must be nq x %d" % self.dim)
+        nq = Q.shape[0]
+        ids = np.full((nq, max(n, 1)), _lib.UINT32_MAX, dtype=np.uint32)
+        counts = np.zeros(nq, dtype=np.uint32)
+        calls, wall = C.c_uint64(), C.c_double()
+        lat = (C.c_double * 5)()
+        check(self._L.hnsw_bench_search_threads(self._h, _p(Q, _f32p), nq, n, ef, int(threads), float(seconds),
+                                                _p(ids, _u32p), _p(counts, _u32p), C.byref(calls), C.byref(wall), lat))
+        return ids[:, :n], counts, calls.value, wall.value, dict(zip(("p50", "p90", "p99", "max", "mean"), list(lat)))
+
     # ---- replication over the GPUs of a node (SURVEY.md section 8e) ------------------------------------
     @staticmethod
     def replicate(index, m, ef_cons, dim, vec_kind, group=None, src=0, device=None, chunk_bytes=1 << 30):

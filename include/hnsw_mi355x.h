@@ -132,7 +132,11 @@ uint64_t hnsw_sharded_slot_bytes(const hnsw_index *h, uint32_t world);
 int hnsw_insert_bulk_sharded(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads, int verbose,
                              const uint8_t *levels, uint32_t rank, uint32_t world, void *d_send, void *d_recv,
                              uint64_t slot_bytes, hnsw_allgather_fn allgather, void *ctx);
-/* HNSW::insert_vec(&mut self, &Vec<f32>) -> Result<NodeID, String>, template.rs:165-173 */
+/* HNSW::insert_vec(&mut self, &Vec<f32>) -> Result<NodeID, String>, template.rs:165-173.  The reference's callers
+ * search right after it (eval_glove/src/main.rs:37-41): when the HBM snapshot is current it is PATCHED -- the new
+ * vector row, its upper-layer base and the adjacency rows the insertion touched go to the device in one staging
+ * copy and one kernel, the arrays growing by a device-to-device copy when they are full -- so an insertion costs
+ * O(rows touched) and the next search finds the snapshot current (hnsw_get_stat "point_patches" / "uploads"). */
 int hnsw_insert_vec(hnsw_index *h, const float *v, uint32_t *out_id);
 int hnsw_insert_vec_level(hnsw_index *h, const float *v, int level /* < 0: draw */, uint32_t *out_id);
 
@@ -148,6 +152,14 @@ int hnsw_import_layer(hnsw_index *h, uint32_t layer, uint64_t n_nodes, const uin
  * No limit on ef, like the reference: up to 1024 the candidate list lives in one wave's registers; beyond that
  * list and visited set live in HBM scratch (hx_search_spill_kernel: the same results, one insertion at a time,
  * orders of magnitude slower -- meant for correctness at the reference's contract, not for throughput). */
+/* Concurrent calls on one handle are COALESCED (the reference takes &self, so its callers are many threads each
+ * blocked in its own call): the first caller to arrive leads a batch, callers arriving with the same (n, ef) before
+ * it is launched park their query in the batch's pinned staging area and sleep; the leader launches one kernel for
+ * all of them and wakes them with their ids.  Every query is still answered by its own wave, so a call returns
+ * exactly what it would return alone.  A lone caller launches at once; a leader that has seen concurrency waits up
+ * to "coalesce_us" (hnsw_set_option; default 30, 0 = never wait, < 0 = coalescing off) for the callers that were
+ * woken together to come back; at most "coalesce_depth" (2) batches are on the GPU at a time and a batch holds at
+ * most "coalesce_max" (1024) queries. */
 int hnsw_search(hnsw_index *h, const float *q, uint32_t n, uint32_t ef, uint32_t *ids,
                 uint32_t *count);
 /* Batched form (new; the reference answers one query per call): Q is nq x dim host memory,
@@ -256,8 +268,15 @@ int hnsw_device_bytes(const hnsw_index *h, uint64_t *bytes);
  *                      one-at-a-time insertion (recall@10 + 0.0006 on the bench's index) for ~0.3 s more per
  *                      1M points; 32768 fills the machine better on indexes of tens of millions of points
  *                      (16M x 256d: 17.1 -> 15.4 s, recall unchanged) and when the insertion searches are
- *                      sharded over several GPUs */
+ *                      sharded over several GPUs
+ *   "coalesce_us", "coalesce_depth", "coalesce_max"
+ *                      the gathering of concurrent hnsw_search calls into one launch, see hnsw_search */
 int hnsw_set_option(hnsw_index *h, const char *key, int64_t value);
+/* counters of the handle: "uploads" (whole-snapshot uploads), "point_patches" (insert_vec calls that patched the
+ * live snapshot), "patch_fallbacks" (those that could not: the next search uploads), "coalesced_batches" /
+ * "coalesced_queries" / "coalesced_max_batch" (launches made for hnsw_search calls, the calls they answered, the
+ * largest batch) */
+int hnsw_get_stat(const hnsw_index *h, const char *key, uint64_t *out);
 
 /* ---- replication of the HBM snapshot over the GPUs of a node ----------------------------------- */
 /* The search path replicates the index per GPU (the reference keeps one index in
@@ -291,6 +310,14 @@ int hnsw_synth_rows(int recipe, uint64_t seed, uint64_t first_row, uint64_t n, u
 /* the level sampler used when levels are not given: believed-equivalent restatement of rand
  * 0.8.5 StdRng::seed_from_u64(0) -> gen::<f32>() -> floor(-ln(r) * ml) (points.rs:39-48,148-160) */
 int hnsw_draw_levels(uint32_t m, uint64_t n, uint8_t *out);
+/* The reference's call pattern as a load: `threads` host threads, each blocked in its own hnsw_search call
+ * (ann_by_vector(&self, ...), template.rs:306-335, one query per call).  Thread t answers queries t, t + T, ... of
+ * Q (nq x dim) again and again until `seconds` have passed and every query has been answered at least once.
+ * ids (nq x n) / counts (nq, may be NULL) receive each query's last answer, *calls the number of completed calls,
+ * *wall_s the elapsed time, lat_us[5] = {p50, p90, p99, max, mean} of the per-call latency in microseconds. */
+int hnsw_bench_search_threads(hnsw_index *h, const float *Q, uint64_t nq, uint32_t n, uint32_t ef, uint32_t threads,
+                              double seconds, uint32_t *ids, uint32_t *counts, uint64_t *calls, double *wall_s,
+                              double *lat_us);
 
 #ifdef __cplusplus
 }
