@@ -263,6 +263,8 @@ def get_index(c, kind_name):
                                      "edge records per batch (insert_bulk_sharded)" % c.world if sharded_build else
                                      "on-device build on one GPU (insert_bulk_device)"),
                             "host_threads": c.build_threads}
+            if not a.cpu_build:
+                c.build_info["device_counters"] = build_counters(index, a.dim, kind_name)
             log("built the %s index (%s, %d host threads) in %.1fs, %d layers" % (
                 kind_name, c.build_info["form"], c.build_threads, build_s, index.nb_layers()))
             if a.config != 4 and c.rank == 0 and a.n_points <= 20_000_000:
@@ -285,6 +287,25 @@ def get_index(c, kind_name):
         index.upload()
     log("rank %d: %s index resident in HBM, %.1f MB" % (c.rank, kind_name, index.device_bytes() / 1e6))
     return index, tag
+
+
+def build_counters(index, d, kind_name):
+    """What the on-device build of `index` read and how long its kernels ran (hnsw_get_stat "build_*"; this rank's
+    share of the insertion searches when the build is sharded).  Algorithmic bytes of the build, the figure
+    `build_roofline.achieved` uses: every vector row the insertion searches and the heuristic read (distance
+    evaluations + staged rows, inserter.rs:40-126 / searcher.rs:109-153) x the un-padded row bytes, + 4 B per
+    adjacency row read and per id in it, + 12 B per edge record filed."""
+    g = lambda k: index.stat("build_" + k)
+    row_bytes = (d + 8) if kind_name == "quant8" else 4 * d
+    rows, adj, ids, rec = g("rows_read"), g("adj_rows"), g("adj_ids"), g("records")
+    pts = max(1, g("points"))
+    return {"points": pts, "batches": g("batches"), "rows_read": rows, "adj_rows_read": adj, "adj_ids_read": ids,
+            "edge_records": rec, "removals": g("removals"), "row_bytes": row_bytes,
+            "algorithmic_bytes": rows * row_bytes + 4 * adj + 4 * ids + 12 * rec,
+            "per_point": {"rows_read": round(rows / pts, 1), "adj_rows_read": round(adj / pts, 1),
+                          "bytes": round((rows * row_bytes + 4 * adj + 4 * ids + 12 * rec) / pts, 1)},
+            "insert_kernel_s": g("insert_kernel_us") / 1e6, "insert_phase_s": g("insert_phase_us") / 1e6,
+            "connect_phases_s": g("connect_us") / 1e6}
 
 
 def choose_ef(c, index, kind_name):
@@ -529,8 +550,61 @@ def extras(c, index, kind_name, ef, local_search):
                                  "efSearch": ef, "entry": "hnsw_search_batch (host pointers; H2D of the queries, D2H of ids / "
                                  "distances / counts / statistics, status check and overflow retry included)",
                                  "note": "never reported as `value`"}
+        # several callers at once (the entry is re-entrant: each call leases its own stream and staging): the H2D of
+        # one call runs under the kernel of another
+        import threading
+        conc = {}
+        for C in (2, 4):
+            gate = threading.Barrier(C + 1)
+
+            def work(t):
+                for i in range(4):  # every caller's stream and staging exist before the clock starts
+                    index.search_batch(qh[(i + t) % nqb], n, ef)
+                gate.wait()
+                for i in range(2 * steps):
+                    index.search_batch(qh[(i + t) % nqb], n, ef)
+            th = [threading.Thread(target=work, args=(t,)) for t in range(C)]
+            [t.start() for t in th]
+            gate.wait()
+            t0 = time.perf_counter()
+            [t.join() for t in th]
+            conc[str(C)] = round(C * 2 * steps * B / (time.perf_counter() - t0), 1)
+        out["pcie_inclusive"]["queries_per_s_concurrent_callers"] = conc
     except Exception as e:
         log("pcie-inclusive measurement skipped: %s" % e)
+    # ---- the reference's own call pattern: ONE query per call, T host threads each blocked in its call
+    # (ann_by_vector(&self, ...), template.rs:306-335) through hnsw_search, the entry the Rust shim binds ----
+    if a.config == 1:
+        try:
+            qs = np.ascontiguousarray(c.queries.reshape(nqb, -1, a.dim)[:, :B].reshape(-1, a.dim))
+            want, _, want_c, _ = index.search_batch(qs, n, ef)  # (the batch path is held to the oracle in `parity`)
+            legs = []
+            lat1 = None
+            for T, window in ((1, 30), (16, 30), (64, 30), (256, 30), (1024, 30), (16, -1)):
+                index.set_option("coalesce_us", window)
+                keys = ("coalesced_batches", "coalesced_queries")
+                s0 = [index.stat(k) for k in keys]
+                ids, counts, calls, wall, lat = index.search_threads(qs, n, ef, T, 1.0)
+                nb, nqd = (index.stat(k) - x for k, x in zip(keys, s0))
+                if T == 1:
+                    lat1 = lat["p50"]
+                legs.append({"threads": T, "coalescing": "off (every call launches by itself)" if window < 0 else "on",
+                             "queries_per_s": round(calls / wall, 1), "p50_us": round(lat["p50"], 1),
+                             "p99_us": round(lat["p99"], 1), "mean_batch": round(nqd / nb, 2) if nb else 1.0,
+                             "host_cpu_cores_used": round((lat["cpu_user_s"] + lat["cpu_sys_s"]) / wall, 2),
+                             "ceiling_threads_over_one_call_latency": round(T / (lat1 * 1e-6), 1) if lat1 else None,
+                             "answers_identical_to_batch_path": bool(np.array_equal(ids, want) and np.array_equal(counts, want_c))})
+            index.set_option("coalesce_us", 30)
+            out["single_query_api"] = {
+                "entry": "hnsw_search (one query per call, the shim's ann_by_vector); T threads of hnsw_bench_search_threads, "
+                         "1 s each over the %d bench queries" % len(qs),
+                "efSearch": ef, "legs": legs,
+                "note": "a call cannot return before its own query's dependent chain of expansions has run (p50 at one "
+                        "thread); T blocked callers therefore answer at most T / that latency per second whatever the "
+                        "GPU could do with more queries in flight (Little's law) -- the ceiling column.  The CPU oracle's "
+                        "threads are in cpu_baseline."}
+        except Exception as e:
+            log("single-query measurement skipped: %s" % e)
     # ---- recipe B (isotropic clusters): qps at the first efSearch that reaches the recall ----
     if a.config == 1 and a.recipe == 0:
         try:
@@ -721,13 +795,73 @@ def main():
             bi = c.build_info
             out["search_after_build"] = {"queries_per_s": out["value"], "ms_per_step": out["ms_per_step"], "steps": K,
                                          "warmup": W, "efSearch": ef, "note": "search rate of the index this run built"}
+            sharded = "insert_bulk_sharded" in bi["form"]
             out["metric"] = ("points/sec inserted, index build %d x %dd fp32 (BASELINE configs[4]: on-device insert / "
-                             "search_layer, insertion searches sharded over the ranks, RCCL all-gather of the new edges; "
-                             "recall@10 of the built index reported)" % (N, d))
+                             "search_layer; %s; recall@10 of the built index reported)" % (
+                                 N, d, ("insertion searches sharded over %d ranks, one RCCL all-gather of the new edge records "
+                                        "per batch" % world) if sharded else
+                                 "ONE GPU, insert_bulk_device: the sharded path (insert_bulk_sharded, RCCL all-gather) was NOT "
+                                 "exercised by this run"))
             out["value"], out["unit"] = bi["points_per_s"], "points/s"
             out["steps"], out["warmup"], out["ms_per_step"] = 1, 0, round(bi["seconds"] * 1e3, 3)
             out["scaling"] = "strong"
-            out["config"]["parallelism"] = "every rank holds a replica; insertion searches of each batch split over %d GPU(s)" % world
+            out["config"]["parallelism"] = (("every rank holds a replica; insertion searches of each batch split over %d GPUs, "
+                                             "edge records all-gathered over RCCL" % world) if sharded else
+                                            "one GPU, no ranks, no collective (the build ran as %s)" % bi["form"])
+            # the roofline of the headline value's dominant kernel (hx_insert_kernel) and the CPU build beside it;
+            # `roofline` / `cpu_baseline` above describe the SEARCH on the index this run built
+            out["search_roofline_note"] = "`roofline`, `cpu_baseline`, `parity`, `recall_*` describe the search on the built index; the build's own are `build_roofline` and `cpu_build_baseline`"
+            dc = bi.get("device_counters")
+            if dc and dc["insert_kernel_s"] > 0:
+                ach = dc["algorithmic_bytes"] / dc["insert_kernel_s"] / 1e9
+                btraffic, bfrom = None, None
+                tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+                try:
+                    tdoc = json.load(open(tfile))
+                    for tj in tdoc.get("entries", []):
+                        if tj.get("workload") == tag and tj.get("kernel") == "hx_insert_kernel":
+                            if tdoc.get("kernel_sources_sha16") == kernel_sources_sha16():
+                                btraffic = tj.get("hbm_bytes_all_launches")
+                                bfrom = {"commit": tdoc.get("commit"), "profile": tj.get("profile", tdoc.get("profile"))}
+                            else:
+                                bfrom = {"stale": "kernels changed since commit %s" % tdoc.get("commit")}
+                except (OSError, ValueError, AttributeError):
+                    pass
+                out["build_roofline"] = {
+                    "bound": "hbm", "kernel": "hx_insert_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": btraffic, "traffic_measured_at": bfrom,
+                    "kernel_s": round(dc["insert_kernel_s"], 3),
+                    "kernel_s_note": "sum of the insert kernel's launches, one HIP event pair around each, on its stream%s" % (
+                        " (rank 0's share of the insertion searches)" if sharded else ""),
+                    "algorithmic_bytes": dc["algorithmic_bytes"], "launches": dc["batches"],
+                    "algorithmic_bytes_note": "rows read by the insertion searches and the heuristic (distance evaluations + "
+                                              "staged rows) x %d B + 4 B per adjacency row and per id read + 12 B per edge "
+                                              "record filed, counted by the kernel itself" % dc["row_bytes"],
+                    "per_point": dc["per_point"],
+                    "share_of_build": round(dc["insert_kernel_s"] / bi["seconds"], 3),
+                    "other_phases_s": {"sort_connect_remove": round(dc["connect_phases_s"], 3),
+                                       "host_and_transfers": round(bi["seconds"] - dc["insert_kernel_s"] - dc["connect_phases_s"], 3)}}
+            if world == 1 and not args.no_cpu_baseline:
+                try:
+                    T_share, hw, quota = cpu_share()
+                    T = args.cpu_threads or T_share
+                    n_cpu = min(N, int(os.environ.get("HNSW_BENCH_CPU_BUILD_POINTS", "1000000")))
+                    rows_cpu = make_rows(args, 0x5EED0001, 0, n_cpu, min(32, c.ncpu))
+                    cpu_idx = H.HNSW.new(m, args.ef_cons, d, H.VEC_QUANT8 if args.kind == "quant8" else H.VEC_F32)
+                    t0 = time.time()
+                    cpu_idx.insert_bulk(rows_cpu, T, False)
+                    cpu_s = time.time() - t0
+                    del cpu_idx, rows_cpu
+                    out["cpu_build_baseline"] = {
+                        "value": round(n_cpu / cpu_s, 1), "unit": "points/s", "cores": T, "kind": "port",
+                        "sample": "the first %d of the %d rows inserted by the library's host insert_bulk (the reference's "
+                                  "algorithm and threading, template.rs:388-444: one thread pool per layer, per-row locks) on "
+                                  "%d threads = %.1f s; a smaller index is cheaper per point (the searches are shorter), so "
+                                  "this flatters the CPU" % (n_cpu, N, T, cpu_s),
+                        "hardware_concurrency": hw, "cpu_quota": quota}
+                    log("cpu build baseline: %d points in %.1fs on %d threads" % (n_cpu, cpu_s, T))
+                except Exception as e:
+                    log("cpu build baseline skipped: %s" % e)
         if world == 1 and not args.no_extras:
             out.update(extras(c, index, args.kind, ef, local_search))
         # ---- the other vector kind, same run (single GPU only) ---------------------------------------

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <linux/futex.h>
+#include <sys/resource.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -45,43 +46,73 @@ struct SearchScratch {
 
 // ---- coalescing of concurrent one-query calls (hnsw_search = the shim's ann_by_vector) ------------------------
 // The reference answers ONE query per call and takes &self, so its callers are many threads each blocked in its
-// own call (template.rs:306-335).  A lone query is a lone wave: 130-190 us on a machine that answers 1024 queries in
-// the same time.  Concurrent calls on one handle are therefore gathered: the first caller to arrive opens a batch and
-// becomes its leader, later callers with the same (n, ef) copy their query into the batch's pinned staging area and
-// sleep on the batch's futex word; the leader launches ONE kernel for everything that arrived, hands every caller
-// its ids and wakes them.  Every query of a batch is answered by its own wave exactly as a lone query would be,
-// so the result of a call does not depend on what it was batched with.
+// own call (template.rs:306-335).  A lone query is a lone wave: ~130 us on a machine that answers 1024 queries in
+// the same time.  Concurrent calls on one handle are therefore gathered: a caller claims a slot of the open batch
+// (one compare-and-swap on the batch's word: no lock on this path -- hundreds of callers taking turns on a mutex
+// that each holds for 100 ns spend their time in futex hand-offs, measured: 256 callers, 15 cores of system time),
+// copies its query into the batch's pinned staging area and sleeps on one of the batch's futex words; the caller
+// that claimed slot 0 is the batch's LEADER: it closes the batch, launches ONE kernel for everything that arrived,
+// hands every caller its ids and wakes them.  Every query of a batch is answered by its own wave exactly as a lone
+// query would be, so the result of a call does not depend on what it was batched with.
 //   window:  a leader that has seen concurrency (the previous batch held more than one query) waits up to
 //            `window_us` for the callers that were woken together with it to come back; a lone caller never waits.
 //   depth:   at most `depth` batches are on the GPU at once; leaders beyond that keep collecting arrivals.
+struct SpinLock {  // the slow paths' lock: a short spin, then sleep on the word (free / held / held with sleepers)
+    std::atomic<uint32_t> v{0};
+    void lock() {
+        for (int spins = 0; spins < 128; spins++) {
+            uint32_t exp = 0;
+            if (v.load(std::memory_order_relaxed) == 0 && v.compare_exchange_weak(exp, 1, std::memory_order_acquire)) return;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        while (v.exchange(2, std::memory_order_acquire) != 0)
+            (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&v), FUTEX_WAIT_PRIVATE, 2, nullptr, nullptr, 0);
+    }
+    void unlock() {
+        if (v.exchange(0, std::memory_order_release) == 2)
+            (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&v), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
+    }
+};
+
 struct CoBatch {
     SearchScratch s;
-    size_t p_q = 0, p_out = 0, r_ids = 0, r_counts = 0, r_stats = 0;  // pinned arena offsets (HostSearchPlan)
-    uint32_t cap = 0, n = 0, ef = 0, dim = 0;
-    std::atomic<uint32_t> count{0};  // queries filed (written under Coalescer::mu, read by the spinning leader)
-    uint32_t wake_at = 0;            // a follower that brings count to this value wakes the leader
-    uint64_t ticket = 0;
+    size_t p_q = 0, p_out = 0;  // pinned arena offsets (HostSearchPlan for `cap` queries)
+    // (n, ef, dim, cap) of this incarnation; written before the word's generation is bumped, read by joiners
+    std::atomic<uint32_t> cap{0}, n{0}, ef{0}, dim{0};
+    // bits 0..15: slots claimed; bit 16: closed (no more joins); bits 32..63: generation (a batch is reused).
+    // A joiner's compare-and-swap succeeds only on the word it read its parameters under.
+    static constexpr uint64_t COUNT = 0xFFFFull, CLOSED = 1ull << 16, GEN = 1ull << 32;
+    std::atomic<uint64_t> word{CLOSED};
+    std::atomic<uint32_t> filed{0};  // claimed slots whose query and request are in place
     struct Req {
         uint32_t *ids, *count;
     };
     std::vector<Req> reqs;
-    std::atomic<uint32_t> done{0};     // futex word: 0 = collecting / running, 1 = results handed out
+    // futex words, 0 = collecting / running, 1 = results handed out; callers spread over them by slot
+    struct alignas(64) Word {
+        std::atomic<uint32_t> v{0};
+    };
+    static constexpr uint32_t WORDS = 16;
+    Word done[WORDS];
     std::atomic<uint32_t> readers{0};  // followers that have not picked up their status yet
     int rc = HNSW_OK;                  // batch-level failure (launch, copy), with its text
     std::string err;
     std::vector<int32_t> status;       // per query
 };
 struct Coalescer {
-    std::mutex mu;
-    std::condition_variable cv;  // leaders wait here for their turn
-    std::vector<CoBatch *> open;
+    std::atomic<CoBatch *> fast{nullptr};  // the open batch callers try first (the latest parameters seen)
+    SpinLock mu;                           // everything below; callers on the fast path never take it
+    std::condition_variable_any cv;        // leaders wait here for a place on the GPU
+    std::vector<CoBatch *> open;           // every open batch, `fast` included
     std::vector<std::unique_ptr<CoBatch>> all;
     std::vector<CoBatch *> idle;
-    uint64_t next_ticket = 0, serving = 0;
-    uint32_t in_flight = 0, last_size = 1;
+    uint32_t in_flight = 0;
+    std::atomic<uint32_t> last_size{1};
     // options "coalesce_us" (< 0: off, every call launches by itself), "coalesce_depth", "coalesce_max"
-    int64_t window_us = 30;
-    uint32_t depth = 2, cap = 1024;
+    std::atomic<int64_t> window_us{30};
+    uint32_t depth = 3, cap = 1024;
     std::atomic<uint64_t> n_batches{0}, n_queries{0}, max_batch{0};
     // where a leader's time goes, in ns (hnsw_get_stat "coalesce_ns_window" / "_turn" / "_gpu" / "_handout")
     std::atomic<uint64_t> ns_window{0}, ns_turn{0}, ns_gpu{0}, ns_handout{0};
@@ -111,6 +142,12 @@ struct hnsw_index {
     Coalescer co;
     // counters behind hnsw_get_stat
     std::atomic<uint64_t> n_uploads{0}, n_point_patches{0}, n_patch_fallbacks{0};
+    // the on-device builds of this handle, summed (hnsw_get_stat "build_*"): what the insert kernel read -- the
+    // build's algorithmic bytes -- and how long it and the connect phases ran
+    struct BuildStats {
+        uint64_t points = 0, batches = 0, rows_read = 0, adj_rows = 0, adj_ids = 0, records = 0, removals = 0;
+        double insert_kernel_s = 0, insert_phase_s = 0, connect_s = 0;
+    } build;
 };
 
 namespace {
@@ -151,22 +188,47 @@ int reject_replica(const hnsw_index *h, const char *what) {
 // The cosine option on the way in: a unit-length copy of n rows, by the same operations in the same order as
 // hx_normalise_rows_kernel (metric.hip) -- one left-to-right f32 sum of squares, correctly rounded sqrt and
 // division, no FMA (this file is compiled with -ffp-contract=off).  Returns rows itself when the option is off.
-const float *cosine_rows(const hnsw_index *h, const float *rows, uint64_t n, std::vector<float> &keep) {
-    if (!h->cosine || !rows) return rows;
+int cosine_rows(const hnsw_index *h, const float *&rows, uint64_t n, std::vector<float> &keep, uint32_t nb_threads = 1) {
+    if (!h->cosine || !rows) return HNSW_OK;
     const uint32_t d = h->host->dim;
     keep.resize((size_t)n * d);
-    for (uint64_t i = 0; i < n; i++) {
-        const float *x = rows + i * d;
-        float s = 0.0f;
-        for (uint32_t e = 0; e < d; e++) {
-            const float t = x[e] * x[e];
-            s += t;
+    std::atomic<uint64_t> bad{UINT64_MAX};
+    auto work = [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; i++) {
+            const float *x = rows + i * d;
+            float s = 0.0f;
+            for (uint32_t e = 0; e < d; e++) {
+                const float t = x[e] * x[e];
+                s += t;
+            }
+            const float nrm = sqrtf(s);
+            // a row without a direction (all zero, or a sum of squares that under- / overflows f32) cannot be put on
+            // the unit sphere: refused here by name instead of poisoning distances with inf - inf later
+            if (!(nrm > 0.0f) || !std::isfinite(nrm)) {
+                uint64_t cur = bad.load();
+                while (i < cur && !bad.compare_exchange_weak(cur, i)) {
+                }
+                return;
+            }
+            float *y = &keep[(size_t)i * d];
+            for (uint32_t e = 0; e < d; e++) y[e] = x[e] / nrm;
         }
-        const float nrm = sqrtf(s);
-        float *y = &keep[(size_t)i * d];
-        for (uint32_t e = 0; e < d; e++) y[e] = x[e] / nrm;
+    };
+    const unsigned nt = (unsigned)std::min<uint64_t>(std::max(1u, nb_threads), std::max<uint64_t>(1, n / 4096));
+    if (nt <= 1) {
+        work(0, n);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+        for (auto &t : th) t.join();
     }
-    return keep.data();
+    if (bad.load() != UINT64_MAX) {
+        set_error("row %llu has no direction (zero, NaN, or a norm outside f32's range): the cosine metric cannot place it",
+                  (unsigned long long)bad.load());
+        return HNSW_ERR_NAN_INPUT;
+    }
+    rows = keep.data();
+    return HNSW_OK;
 }
 // ... and for queries already copied to the device
 int cosine_queries(const hnsw_index *h, void *d_Q, uint64_t nq, hipStream_t stream) {
@@ -356,15 +418,30 @@ int search_staged(hnsw_index *h, SearchScratch &s, const HostSearchPlan &p, hx::
     const hx::DevView &v = h->dev.view;
     unsigned char *dv = static_cast<unsigned char *>(s.dev), *hv = static_cast<unsigned char *>(s.pin);
     int rc;
-    HIP_TRY(hipMemcpyAsync(dv + p.o_q, Q_user ? (const void *)Q_user : (const void *)(hv + p.p_q), nq * v.dim * 4,
-                           hipMemcpyHostToDevice, s.stream));
-    if ((rc = cosine_queries(h, dv + p.o_q, nq, s.stream))) return rc;
+    // Small calls skip both copies: pinned host memory is mapped into the device's address space, the kernel reads
+    // each query once (400 B per wave over the link) and writes its few result words straight into the pinned
+    // result block.  Measured on the 1M x 100d index: a lone 1024-query call 225 us against 232 us with the copies, but
+    // 2 / 3 concurrent 1024-query callers 5.2 / 7.5 M q/s against 5.9 / 8.0 M (the copy engines overlap with the other
+    // caller's kernel, reads over the link from a busy kernel do not) -- so calls of up to 512 queries (every coalesced
+    // batch of up to 512 callers) go without copies, larger ones, and calls whose queries are normalised on the
+    // device first (the cosine option), keep them.
+    static const bool zc_allowed = !(getenv("HNSW_MI355X_ZERO_COPY") && atoi(getenv("HNSW_MI355X_ZERO_COPY")) == 0);
+    static const uint64_t zc_max = getenv("HNSW_MI355X_ZERO_COPY_MAX") ? strtoull(getenv("HNSW_MI355X_ZERO_COPY_MAX"), nullptr, 0) : 512;
+    const bool zc = zc_allowed && !Q_user && !h->cosine && nq <= zc_max;
     hx::SearchArgs a = a_host;
-    a.Q = reinterpret_cast<const float *>(dv + p.o_q);
-    a.out_ids = reinterpret_cast<uint32_t *>(dv + p.o_out + p.r_ids);
-    a.out_dists = reinterpret_cast<float *>(dv + p.o_out + p.r_dists);
-    a.out_counts = reinterpret_cast<uint32_t *>(dv + p.o_out + p.r_counts);
-    a.out_stats = reinterpret_cast<hnsw_query_stats *>(dv + p.o_out + p.r_stats);
+    unsigned char *ob = zc ? hv + p.p_out : dv + p.o_out;  // where the kernel writes the result block
+    if (zc) {
+        a.Q = reinterpret_cast<const float *>(hv + p.p_q);
+    } else {
+        HIP_TRY(hipMemcpyAsync(dv + p.o_q, Q_user ? (const void *)Q_user : (const void *)(hv + p.p_q), nq * v.dim * 4,
+                               hipMemcpyHostToDevice, s.stream));
+        if ((rc = cosine_queries(h, dv + p.o_q, nq, s.stream))) return rc;
+        a.Q = reinterpret_cast<const float *>(dv + p.o_q);
+    }
+    a.out_ids = reinterpret_cast<uint32_t *>(ob + p.r_ids);
+    a.out_dists = reinterpret_cast<float *>(ob + p.r_dists);
+    a.out_counts = reinterpret_cast<uint32_t *>(ob + p.r_counts);
+    a.out_stats = reinterpret_cast<hnsw_query_stats *>(ob + p.r_stats);
     if (entries) {
         HIP_TRY(hipMemcpyAsync(dv + p.o_ent, entries, (size_t)a.n_entry * 4, hipMemcpyHostToDevice, s.stream));
         a.entries = reinterpret_cast<const uint32_t *>(dv + p.o_ent);
@@ -377,7 +454,7 @@ int search_staged(hnsw_index *h, SearchScratch &s, const HostSearchPlan &p, hx::
     while (true) {
         rc = hx::launch_search(v, a, (uint32_t)nrun, slots, s.stream);
         if (rc != HNSW_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(hv + p.p_out, dv + p.o_out, p.out_bytes, hipMemcpyDeviceToHost, s.stream));
+        if (!zc) HIP_TRY(hipMemcpyAsync(hv + p.p_out, dv + p.o_out, p.out_bytes, hipMemcpyDeviceToHost, s.stream));
         HIP_TRY(hipStreamSynchronize(s.stream));
         sel.clear();
         for (uint64_t i = 0; i < nq; i++)
@@ -428,12 +505,16 @@ inline void futex_wait(std::atomic<uint32_t> *w, uint32_t while_equals) {
     while (w->load(std::memory_order_acquire) == while_equals)
         (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, while_equals, nullptr, nullptr, 0);
 }
-inline void futex_wake_all(std::atomic<uint32_t> *w) {
-    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+// Waking n sleepers from one thread costs that thread n wake-ups one after the other (a hundred microseconds for
+// a hundred callers): the leader wakes two, and every caller that wakes up wakes two more.  The word is already 1
+// by then, so a caller that was not asleep yet never goes to sleep and no wake-up can be lost.
+inline void futex_wake(std::atomic<uint32_t> *w, int n) {
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, n, nullptr, nullptr, 0);
 }
 
-// scratch of a batch sized for `cap` queries of (dim, n); called under Coalescer::mu
-int cobatch_prepare(hnsw_index *h, CoBatch &b, uint32_t cap, uint32_t n, uint32_t ef) {
+// a batch from the pool made ready for a new incarnation with `claimed` slots already taken (1: the caller leads
+// it; 0: a leaderless successor whose first joiner will); called under Coalescer::mu
+int cobatch_open(hnsw_index *h, CoBatch &b, uint32_t cap, uint32_t n, uint32_t ef, uint32_t claimed) {
     const uint32_t d = h->dev.view.dim;
     const HostSearchPlan p = plan_host_search(cap, d, n, 0);
     SearchScratch &s = b.s;
@@ -463,103 +544,160 @@ int cobatch_prepare(hnsw_index *h, CoBatch &b, uint32_t cap, uint32_t n, uint32_
     }
     b.p_q = p.p_q;
     b.p_out = p.p_out;
-    b.r_ids = p.r_ids;
-    b.r_counts = p.r_counts;
-    b.r_stats = p.r_stats;
-    b.cap = cap;
-    b.n = n;
-    b.ef = ef;
-    b.dim = d;
-    b.count.store(0, std::memory_order_relaxed);
-    b.wake_at = 0;
-    b.done.store(0, std::memory_order_relaxed);
+    b.cap.store(cap, std::memory_order_relaxed);
+    b.n.store(n, std::memory_order_relaxed);
+    b.ef.store(ef, std::memory_order_relaxed);
+    b.dim.store(d, std::memory_order_relaxed);
+    b.filed.store(0, std::memory_order_relaxed);
+    for (auto &w : b.done) w.v.store(0, std::memory_order_relaxed);
     b.readers.store(0, std::memory_order_relaxed);
     b.rc = HNSW_OK;
     b.err.clear();
     if (b.reqs.size() < cap) b.reqs.resize(cap);
     if (b.status.size() < cap) b.status.resize(cap);
+    const uint64_t gen = (b.word.load(std::memory_order_relaxed) >> 32) + 1;
+    b.word.store((gen << 32) | claimed, std::memory_order_release);  // open
     return HNSW_OK;
 }
 
+// claim a slot of an open batch with these parameters: the slot, or -1 (closed, full, other parameters)
+inline int cobatch_join(CoBatch *b, uint32_t n, uint32_t ef, uint32_t d) {
+    uint64_t w = b->word.load(std::memory_order_acquire);
+    while (true) {
+        if ((w & CoBatch::CLOSED) || (w & CoBatch::COUNT) >= b->cap.load(std::memory_order_relaxed)) return -1;
+        if (b->n.load(std::memory_order_relaxed) != n || b->ef.load(std::memory_order_relaxed) != ef ||
+            b->dim.load(std::memory_order_relaxed) != d)
+            return -1;
+        // succeeds only if the word is still the one the parameters were read under (same generation, still open)
+        if (b->word.compare_exchange_weak(w, w + 1, std::memory_order_acq_rel, std::memory_order_acquire))
+            return (int)(w & CoBatch::COUNT);
+    }
+}
+
+// the snapshot is what the host index holds (read without the handle's lock: nothing may mutate an index while
+// it is being searched, include/hnsw_mi355x.h)
+inline bool snapshot_current(const hnsw_index *h) {
+    return h->dev.valid && (h->dev.replica || h->dev.version_seen == h->host->version);
+}
+
 int search_coalesced(hnsw_index *h, const float *q, uint32_t n, uint32_t ef, uint32_t *ids, uint32_t *count) {
-    int rc = ensure_uploaded(h);
-    if (rc != HNSW_OK) return rc;
+    int rc;
+    if (!snapshot_current(h) && (rc = ensure_uploaded(h)) != HNSW_OK) return rc;
     Coalescer &co = h->co;
     const uint32_t d = h->dev.view.dim;
-    std::unique_lock<std::mutex> lk(co.mu);
-    CoBatch *b = nullptr;
-    for (CoBatch *o : co.open)
-        if (o->n == n && o->ef == ef && o->dim == d && o->count.load(std::memory_order_relaxed) < o->cap) {
-            b = o;
-            break;
+    // ---- claim a slot: the open batch everybody looks at first, else (under the lock) any open batch with these
+    // parameters, else a new batch which this caller leads ----
+    CoBatch *b = co.fast.load(std::memory_order_acquire);
+    int slot = b ? cobatch_join(b, n, ef, d) : -1;
+    if (slot < 0) {
+        std::lock_guard<SpinLock> g(co.mu);
+        for (CoBatch *o : co.open)
+            if ((slot = cobatch_join(o, n, ef, d)) >= 0) {
+                b = o;
+                break;
+            }
+        if (slot < 0) {
+            // a leaderless batch nobody joined (other parameters) is taken out of circulation rather than left open
+            for (size_t i = 0; i < co.open.size();) {
+                CoBatch *o = co.open[i];
+                uint64_t w = o->word.load(std::memory_order_acquire);
+                if ((w & CoBatch::COUNT) == 0 && !(w & CoBatch::CLOSED) &&
+                    o->word.compare_exchange_strong(w, w | CoBatch::CLOSED, std::memory_order_acq_rel)) {
+                    co.open.erase(co.open.begin() + i);
+                    co.idle.push_back(o);
+                    if (co.fast.load(std::memory_order_relaxed) == o) co.fast.store(nullptr, std::memory_order_release);
+                } else {
+                    i++;
+                }
+            }
+            if (!co.idle.empty()) {
+                b = co.idle.back();
+                co.idle.pop_back();
+            } else {
+                co.all.emplace_back(new CoBatch());
+                b = co.all.back().get();
+            }
+            if ((rc = cobatch_open(h, *b, co.cap, n, ef, 1)) != HNSW_OK) {
+                co.idle.push_back(b);
+                return rc;
+            }
+            slot = 0;
+            co.open.push_back(b);
+            co.fast.store(b, std::memory_order_release);
         }
-    const bool leader = b == nullptr;
-    if (leader) {
-        if (!co.idle.empty()) {
-            b = co.idle.back();
-            co.idle.pop_back();
-        } else {
-            co.all.emplace_back(new CoBatch());
-            b = co.all.back().get();
-        }
-        if ((rc = cobatch_prepare(h, *b, co.cap, n, ef)) != HNSW_OK) {
-            co.idle.push_back(b);
-            return rc;
-        }
-        b->ticket = co.next_ticket++;
-        co.open.push_back(b);
     }
-    const uint32_t slot = b->count.load(std::memory_order_relaxed);
     memcpy(static_cast<unsigned char *>(b->s.pin) + b->p_q + (size_t)slot * d * 4, q, (size_t)d * 4);
     b->reqs[slot] = CoBatch::Req{ids, count};
-    b->count.store(slot + 1, std::memory_order_release);
+    b->filed.fetch_add(1, std::memory_order_release);
 
-    if (!leader) {
-        if (slot + 1 == b->wake_at) co.cv.notify_all();
-        lk.unlock();
-        futex_wait(&b->done, 0);
+    if (slot != 0) {
+        std::atomic<uint32_t> *word = &b->done[slot % CoBatch::WORDS].v;
+        futex_wait(word, 0);
+        futex_wake(word, 2);
         int my = b->rc;
         if (my != HNSW_OK)
             set_error("%s", b->err.c_str());
         else
             my = query_status_error(0, b->status[slot]);
         if (b->readers.fetch_sub(1, std::memory_order_acq_rel) == 1) {  // the last one out returns the batch
-            std::lock_guard<std::mutex> g(co.mu);
+            std::lock_guard<SpinLock> g(co.mu);
             co.idle.push_back(b);
         }
         return my;
     }
 
-    // ---- leader ----
+    // ---- leader (slot 0) ----
     using sclk = std::chrono::steady_clock;
     auto ns_since = [](sclk::time_point t) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(sclk::now() - t).count(); };
     const auto t_lead = sclk::now();
-    if (co.window_us > 0 && co.last_size > 1) {
+    const int64_t window_us = co.window_us.load(std::memory_order_relaxed);
+    const uint32_t last = co.last_size.load(std::memory_order_relaxed);
+    if (window_us > 0 && last > 1) {
         // callers woken together come back together: wait for as many as the previous batch held, at most the
         // window (spinning: a timed sleep of tens of microseconds wakes up 50 us late)
-        const uint32_t target = std::min(co.last_size, b->cap);
-        lk.unlock();
-        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(co.window_us);
-        while (b->count.load(std::memory_order_acquire) < target && std::chrono::steady_clock::now() < deadline) {
+        const uint32_t target = std::min(last, b->cap.load(std::memory_order_relaxed));
+        const auto deadline = t_lead + std::chrono::microseconds(window_us);
+        while ((b->word.load(std::memory_order_acquire) & CoBatch::COUNT) < target && sclk::now() < deadline) {
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
         }
-        lk.lock();
     }
-    b->wake_at = b->cap;  // while waiting for a turn, only a full batch is worth a wake-up
     co.ns_window.fetch_add(ns_since(t_lead), std::memory_order_relaxed);
     const auto t_turn = sclk::now();
-    while (!(co.serving == b->ticket && co.in_flight < co.depth)) co.cv.wait(lk);
+    {
+        std::unique_lock<SpinLock> lk(co.mu);
+        while (co.in_flight >= co.depth) co.cv.wait(lk);
+        co.in_flight++;
+        co.open.erase(std::find(co.open.begin(), co.open.end(), b));
+        if (co.fast.load(std::memory_order_relaxed) == b) {
+            // the successor is published BEFORE this batch closes, so that arrivals always find an open batch without
+            // the lock; it has no leader yet: whoever claims its slot 0 will be
+            CoBatch *nx = nullptr;
+            if (!co.idle.empty()) {
+                nx = co.idle.back();
+                co.idle.pop_back();
+            } else {
+                co.all.emplace_back(new CoBatch());
+                nx = co.all.back().get();
+            }
+            if (cobatch_open(h, *nx, co.cap, n, ef, 0) == HNSW_OK) {
+                co.open.push_back(nx);
+                co.fast.store(nx, std::memory_order_release);
+            } else {
+                co.idle.push_back(nx);
+                co.fast.store(nullptr, std::memory_order_release);
+            }
+        }
+    }
     co.ns_turn.fetch_add(ns_since(t_turn), std::memory_order_relaxed);
-    co.open.erase(std::find(co.open.begin(), co.open.end(), b));
-    co.serving++;
-    co.in_flight++;
-    const uint32_t nq = b->count.load(std::memory_order_relaxed);
-    co.last_size = nq;
-    co.cv.notify_all();  // the next ticket may be waiting for `serving`
-    lk.unlock();
-
+    const uint32_t nq = (uint32_t)(b->word.fetch_or(CoBatch::CLOSED, std::memory_order_acq_rel) & CoBatch::COUNT);
+    while (b->filed.load(std::memory_order_acquire) != nq) {  // joiners between their claim and their copy (~100 ns)
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    co.last_size.store(nq, std::memory_order_relaxed);
     co.n_batches.fetch_add(1, std::memory_order_relaxed);
     co.n_queries.fetch_add(nq, std::memory_order_relaxed);
     uint64_t mb = co.max_batch.load(std::memory_order_relaxed);
@@ -572,11 +710,13 @@ int search_coalesced(hnsw_index *h, const float *q, uint32_t n, uint32_t ef, uin
     dummy.nb_layers = h->dev.view.nb_layers;
     hx::SearchArgs a = ann_args(dummy, nullptr, n, ef, nullptr, nullptr, nullptr, nullptr);
     const auto t_gpu = sclk::now();
-    rc = search_staged(h, b->s, p, a, nq, nullptr, nullptr);
+    rc = hipSetDevice(h->dev.device) == hipSuccess ? HNSW_OK : HNSW_ERR_HIP;
+    if (rc != HNSW_OK) set_error("hipSetDevice(%d) failed", h->dev.device);
+    if (rc == HNSW_OK) rc = search_staged(h, b->s, p, a, nq, nullptr, nullptr);
     co.ns_gpu.fetch_add(ns_since(t_gpu), std::memory_order_relaxed);
     const auto t_hand = sclk::now();
     {
-        std::lock_guard<std::mutex> g(co.mu);
+        std::lock_guard<SpinLock> g(co.mu);
         co.in_flight--;
     }
     co.cv.notify_all();
@@ -595,14 +735,16 @@ int search_coalesced(hnsw_index *h, const float *q, uint32_t n, uint32_t ef, uin
             if (b->reqs[i].count) *b->reqs[i].count = o_cnt[i];
             b->status[i] = st[i].status;
         }
-        my = query_status_error(0, b->status[slot]);
+        my = query_status_error(0, b->status[0]);
     }
     if (nq > 1) {
         b->readers.store(nq - 1, std::memory_order_release);
-        b->done.store(1, std::memory_order_release);
-        futex_wake_all(&b->done);
+        for (uint32_t w = 0; w < std::min(nq, CoBatch::WORDS); w++) {
+            b->done[w].v.store(1, std::memory_order_release);
+            futex_wake(&b->done[w].v, 2);
+        }
     } else {
-        std::lock_guard<std::mutex> g(co.mu);
+        std::lock_guard<SpinLock> g(co.mu);
         co.idle.push_back(b);
     }
     co.ns_handout.fetch_add(ns_since(t_hand), std::memory_order_relaxed);
@@ -1013,7 +1155,19 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     }
     const uint32_t REF_CAP = 1u << 20;      // kept-last-edge records of the whole build
     const size_t temp_bytes = hx::sort_temp_bytes(REQ_CAP);
-    DevBuf dLevels, dIds, dOutIds, dOutD, dStatus, dCnt, dKeyA, dKeyB, dValA, dValB, dTemp, dRef;
+    DevBuf dLevels, dIds, dOutIds, dOutD, dStatus, dCnt, dKeyA, dKeyB, dValA, dValB, dTemp, dRef, dRead;
+    struct EvPair {  // the insert kernel's launches are timed with HIP events on their stream
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EvPair() {
+            if (a) (void)hipEventDestroy(a);
+            if (b) (void)hipEventDestroy(b);
+        }
+    } ev;
+    HIP_TRY(hipEventCreate(&ev.a));
+    HIP_TRY(hipEventCreate(&ev.b));
+    double t_kernel_ms = 0;
+    if ((rc = dRead.alloc(32))) return rc;
+    HIP_TRY(hipMemset(dRead.p, 0, 32));
     if ((rc = dLevels.alloc(host.len())) || (rc = dIds.alloc(BMAX * 4)) ||
         (rc = dOutIds.alloc((size_t)BMAX * L * m * 4)) || (rc = dOutD.alloc((size_t)BMAX * L * m * 4)) ||
         (rc = dStatus.alloc(BMAX * 4)) || (rc = dCnt.alloc(64)) || (rc = dKeyA.alloc((size_t)REQ_CAP * 8)) ||
@@ -1068,7 +1222,19 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         a.out_status = dStatus.as<int32_t>();
         a.adj0_mut = h->dev.adj0_mut();
         a.adj_up_mut = h->dev.adj_up_mut();
+        a.counters = dRead.as<unsigned long long>();
         uint32_t nreq = 0;
+        auto timed_insert = [&](uint32_t nblocks, int adjust) -> int {
+            HIP_TRY(hipEventRecord(ev.a, nullptr));
+            const int r = hx::launch_insert(v, a, nblocks, nullptr, adjust);
+            if (r != HNSW_OK) return r;
+            HIP_TRY(hipEventRecord(ev.b, nullptr));
+            HIP_TRY(hipEventSynchronize(ev.b));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+            t_kernel_ms += ms;
+            return HNSW_OK;
+        };
         if (!sh) {
             a.req_keys = dKeyA.as<uint64_t>();
             a.req_vals = dValA.as<uint32_t>();
@@ -1077,7 +1243,7 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
             a.req_cap = REQ_CAP;
             HIP_TRY(hipMemset(cnt + 4, 0xFF, 4));  // no reservation has failed yet
             const int first_adjust = hx::insert_table_first_adjust(v, a);
-            rc = hx::launch_insert(v, a, (uint32_t)nb, nullptr, first_adjust);
+            rc = timed_insert((uint32_t)nb, first_adjust);
             if (rc != HNSW_OK) return rc;
             uint32_t c5[5];
             HIP_TRY(hipMemcpy(c5, dCnt.p, 20, hipMemcpyDeviceToHost));  // synchronises
@@ -1096,7 +1262,7 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
             }
             if (!again.empty()) {
                 HIP_TRY(hipMemcpy(dIds.p, again.data(), again.size() * 4, hipMemcpyHostToDevice));
-                rc = hx::launch_insert(v, a, (uint32_t)again.size(), nullptr, std::max(first_adjust, 0) + 1);
+                rc = timed_insert((uint32_t)again.size(), std::max(first_adjust, 0) + 1);
                 if (rc != HNSW_OK) return rc;
                 HIP_TRY(hipMemcpy(c5, dCnt.p, 20, hipMemcpyDeviceToHost));
                 HIP_TRY(hipMemcpy(o_st.data(), dStatus.p, again.size() * 4, hipMemcpyDeviceToHost));
@@ -1126,7 +1292,7 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
             a.req_cap = SLOT_REC;
             a.emit_own = 1;
             const int first_adjust = hx::insert_table_first_adjust(v, a);
-            rc = hx::launch_insert(v, a, (uint32_t)nb, nullptr, first_adjust);
+            if (nb) rc = timed_insert((uint32_t)nb, first_adjust);
             if (rc != HNSW_OK) return rc;
             if (nb) HIP_TRY(hipMemcpy(o_st.data(), dStatus.p, nb * 4, hipMemcpyDeviceToHost));  // synchronises
             std::vector<uint32_t> myfail, again;
@@ -1142,7 +1308,7 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
             }
             if (!again.empty()) {
                 HIP_TRY(hipMemcpy(dIds.p, again.data(), again.size() * 4, hipMemcpyHostToDevice));
-                rc = hx::launch_insert(v, a, (uint32_t)again.size(), nullptr, std::max(first_adjust, 0) + 1);
+                rc = timed_insert((uint32_t)again.size(), std::max(first_adjust, 0) + 1);
                 if (rc != HNSW_OK) return rc;
                 HIP_TRY(hipMemcpy(o_st.data(), dStatus.p, again.size() * 4, hipMemcpyDeviceToHost));
                 for (size_t i = 0; i < again.size(); i++)
@@ -1240,6 +1406,21 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
             fprintf(stderr, "\rBuilding HNSW index on the GPU %zu/%zu", pos, order.size());
     }
 
+    {  // what the build read and how long its kernels ran (hnsw_get_stat "build_*")
+        unsigned long long rd[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(rd, dRead.p, 32, hipMemcpyDeviceToHost));
+        hnsw_index::BuildStats &bs = h->build;
+        bs.points += order.size();
+        bs.batches += n_batches;
+        bs.rows_read += rd[0];
+        bs.adj_rows += rd[1];
+        bs.adj_ids += rd[2];
+        bs.records += n_req;
+        bs.removals += n_rem;
+        bs.insert_kernel_s += t_kernel_ms * 1e-3;
+        bs.insert_phase_s += t_ins;
+        bs.connect_s += t_conn;
+    }
     // ---- the host graph from the device arrays ----
     if (row_reserve.t.joinable()) row_reserve.t.join();
     const auto t_sync0 = std::chrono::steady_clock::now();
@@ -1368,6 +1549,17 @@ int hnsw_clone(const hnsw_index *h, hnsw_index **out) {
     if (!c) return HNSW_ERR_OOM;
     c->host.reset(new hx::HostIndex(*h->host));
     c->device = h->device;
+    // the handle's options travel with the clone (a cosine index that forgot its metric would stop normalising
+    // its queries)
+    c->cosine = h->cosine;
+    c->gpu_build = h->gpu_build;
+    c->build_batch_max = h->build_batch_max;
+    c->build_batch_div = h->build_batch_div;
+    c->dev.inline_rows = h->dev.inline_rows;
+    c->dev.fat_budget_bytes = h->dev.fat_budget_bytes;
+    c->co.window_us.store(h->co.window_us.load());
+    c->co.depth = h->co.depth;
+    c->co.cap = h->co.cap;
     *out = c;
     return HNSW_OK;
 }
@@ -1407,7 +1599,7 @@ int hnsw_insert_bulk_levels(hnsw_index *h, const float *rows, uint64_t n, uint32
     if (is_replica(h)) return reject_replica(h, "hnsw_insert_bulk");
     if (h->incomplete_build) return check_search_args(h, 1);
     std::vector<float> unit;
-    rows = cosine_rows(h, rows, n, unit);
+    if (int crc = cosine_rows(h, rows, n, unit, nb_threads)) return crc;
     if (h->gpu_build == 2) return device_build_guard(h, [&] { return gpu_insert_bulk_full(h, rows, n, nb_threads, verbose, levels); });
     if (h->gpu_build) return device_build_guard(h, [&] { return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels); });
     return h->host->insert_bulk(rows, n, nb_threads, verbose != 0, levels);
@@ -1422,7 +1614,7 @@ int hnsw_insert_bulk_sharded(hnsw_index *h, const float *rows, uint64_t n, uint3
     if (!h || !rows || world == 0 || rank >= world) return HNSW_ERR_ARG;
     if (is_replica(h)) return reject_replica(h, "hnsw_insert_bulk_sharded");
     std::vector<float> unit;
-    rows = cosine_rows(h, rows, n, unit);
+    if (int crc = cosine_rows(h, rows, n, unit, nb_threads)) return crc;
     ShardCtx sh{rank, world, static_cast<unsigned char *>(d_send), static_cast<unsigned char *>(d_recv), slot_bytes,
                 allgather, ctx};
     if (h->incomplete_build) return check_search_args(h, 1);
@@ -1434,7 +1626,7 @@ int hnsw_insert_bulk_device(hnsw_index *h, const float *rows, uint64_t n, uint32
     if (is_replica(h)) return reject_replica(h, "hnsw_insert_bulk_device");
     if (h->incomplete_build) return check_search_args(h, 1);
     std::vector<float> unit;
-    rows = cosine_rows(h, rows, n, unit);
+    if (int crc = cosine_rows(h, rows, n, unit, nb_threads)) return crc;
     if (h->gpu_build == 1) return device_build_guard(h, [&] { return gpu_insert_bulk(h, rows, n, nb_threads, verbose, levels); });
     return device_build_guard(h, [&] { return gpu_insert_bulk_full(h, rows, n, nb_threads, verbose, levels); });
 }
@@ -1446,7 +1638,7 @@ int hnsw_insert_vec_level(hnsw_index *h, const float *v, int level, uint32_t *ou
     if (is_replica(h)) return reject_replica(h, "hnsw_insert_vec");
     if (h->incomplete_build) return check_search_args(h, 1);
     std::vector<float> unit;
-    v = cosine_rows(h, v, 1, unit);
+    if (int crc = cosine_rows(h, v, 1, unit)) return crc;
     // The reference's callers search right after an insert_vec (eval_glove/src/main.rs:37-41).  When the HBM snapshot
     // was current before the insertion it is patched -- the new row and the adjacency rows the insertion touched --
     // instead of being thrown away and uploaded again by the next search (DeviceIndex::append_point).
@@ -1474,7 +1666,7 @@ int hnsw_import_points(hnsw_index *h, const float *rows, uint64_t n, const uint8
     if (!h || !rows) return HNSW_ERR_ARG;
     if (is_replica(h)) return reject_replica(h, "hnsw_import_points");
     std::vector<float> unit;
-    rows = cosine_rows(h, rows, n, unit);
+    if (int crc = cosine_rows(h, rows, n, unit)) return crc;
     return h->host->import_points(rows, n, levels);
 }
 int hnsw_import_layer(hnsw_index *h, uint32_t layer, uint64_t n_nodes, const uint32_t *node_ids,
@@ -1489,7 +1681,7 @@ int hnsw_search(hnsw_index *h, const float *q, uint32_t n, uint32_t ef, uint32_t
                 uint32_t *count) {
     // concurrent callers are gathered into one launch (the coalescer above); ef beyond the register-resident list
     // (the HBM-spill kernel) and result lists of thousands of ids go by themselves
-    if (h && q && ids && n > 0 && n <= 1024 && ef <= 1024 && h->co.window_us >= 0) {
+    if (h && q && ids && n > 0 && n <= 1024 && ef <= 1024 && h->co.window_us.load(std::memory_order_relaxed) >= 0) {
         const int rc = check_search_args(h, ef);
         if (rc != HNSW_OK) return rc;
         return search_coalesced(h, q, n, ef, ids, count);
@@ -1993,9 +2185,9 @@ int hnsw_set_option(hnsw_index *h, const char *key, int64_t value) {
         h->build_batch_div = (uint32_t)std::min<int64_t>(value, 1 << 20);
         return HNSW_OK;
     } else if (!strcmp(key, "coalesce_us") || !strcmp(key, "coalesce_depth") || !strcmp(key, "coalesce_max")) {
-        std::lock_guard<std::mutex> cg(h->co.mu);
+        std::lock_guard<SpinLock> cg(h->co.mu);
         if (!strcmp(key, "coalesce_us")) {
-            h->co.window_us = std::min<int64_t>(value, 100000);
+            h->co.window_us.store(std::min<int64_t>(value, 100000));
         } else if (value < 1) {
             set_error("%s must be positive", key);
             return HNSW_ERR_ARG;
@@ -2025,6 +2217,23 @@ int hnsw_get_stat(const hnsw_index *h, const char *key, uint64_t *out) {
         *out = h->n_point_patches.load();
     } else if (!strcmp(key, "patch_fallbacks")) {
         *out = h->n_patch_fallbacks.load();
+    } else if (!strncmp(key, "build_", 6)) {
+        const hnsw_index::BuildStats &bs = h->build;
+        const char *k = key + 6;
+        if (!strcmp(k, "points")) *out = bs.points;
+        else if (!strcmp(k, "batches")) *out = bs.batches;
+        else if (!strcmp(k, "rows_read")) *out = bs.rows_read;
+        else if (!strcmp(k, "adj_rows")) *out = bs.adj_rows;
+        else if (!strcmp(k, "adj_ids")) *out = bs.adj_ids;
+        else if (!strcmp(k, "records")) *out = bs.records;
+        else if (!strcmp(k, "removals")) *out = bs.removals;
+        else if (!strcmp(k, "insert_kernel_us")) *out = (uint64_t)(bs.insert_kernel_s * 1e6);
+        else if (!strcmp(k, "insert_phase_us")) *out = (uint64_t)(bs.insert_phase_s * 1e6);
+        else if (!strcmp(k, "connect_us")) *out = (uint64_t)(bs.connect_s * 1e6);
+        else {
+            set_error("unknown statistic %s", key);
+            return HNSW_ERR_ARG;
+        }
     } else if (!strcmp(key, "coalesced_batches")) {
         *out = h->co.n_batches.load();
     } else if (!strcmp(key, "coalesced_queries")) {
@@ -2054,7 +2263,8 @@ struct SnapHeader {  // what travels in hnsw_snapshot_desc.header (32 words)
     uint32_t dim, n_points, nb_layers, ep, S0, S1, row_stride, half_bytes, nch4, rem;
     uint32_t fat_stride_lo, fat_stride_hi;
     uint32_t m, ef_cons;
-    uint32_t reserved[15];
+    uint32_t flags;  // bit 0: the cosine option (queries are normalised on arrival)
+    uint32_t reserved[14];
 };
 static_assert(sizeof(SnapHeader) == 32 * 4, "snapshot header is 32 words");
 constexpr uint32_t SNAP_MAGIC = 0x48584E53u;  // "SNXH"
@@ -2092,6 +2302,7 @@ int hnsw_snapshot_describe(hnsw_index *h, hnsw_snapshot_desc *out) {
     hd.fat_stride_hi = (uint32_t)(v.fat_stride >> 32);
     hd.m = (uint32_t)h->host->params.m;
     hd.ef_cons = (uint32_t)h->host->params.ef_cons;
+    hd.flags = h->cosine ? 1u : 0u;
     memcpy(out->header, &hd, sizeof(hd));
     return HNSW_OK;
 }
@@ -2113,10 +2324,22 @@ int hnsw_snapshot_adopt(hnsw_index *h, hnsw_snapshot_desc *d) {
                   hd.kind, hd.m, h->host->dim, h->host->kind, (uint32_t)h->host->params.m);
         return HNSW_ERR_BAD_DIM;
     }
-    // the sizes must be what the header implies: the kernels index these arrays by id without a range check
+    // Every stride in the header is recomputed from the receiving handle's own m, dim and kind and must agree (the
+    // kernels index the arrays by id without a range check, and a zero stride must never reach a division), then
+    // the array sizes must be what the header implies.
+    const bool q8 = h->host->kind == HNSW_VEC_QUANT8;
+    const uint32_t half = q8 ? hx::quant_half_bytes(hd.dim) : 0, stride = q8 ? 2 * half : hx::f32_row_stride(hd.dim);
+    const uint32_t S0 = hx::adj_stride(h->host->layer_m(0), 32), S1 = hx::adj_stride(h->host->params.m, 8);
+    const uint64_t fat_stride = ((uint64_t)hd.fat_stride_hi << 32) | hd.fat_stride_lo;
+    if (hd.S0 != S0 || hd.S1 != S1 || hd.row_stride != stride || hd.half_bytes != half || hd.nch4 != 4 * (hd.dim / 8) ||
+        hd.rem != hd.dim % 8 || (fat_stride != 0 && fat_stride != (uint64_t)S0 * stride)) {
+        set_error("hnsw_snapshot_adopt: the header's strides are not those of a %ud kind-%d m=%u index", hd.dim, hd.kind, hd.m);
+        return HNSW_ERR_ARG;
+    }
     const uint64_t N = hd.n_points;
-    if (N == 0 || d->bytes[0] != N * hd.row_stride || d->bytes[1] != N * hd.S0 * 4ull || d->bytes[3] != N * 4ull ||
-        d->bytes[2] == 0 || d->bytes[2] % (hd.S1 * 4ull) != 0 || d->bytes[4] < 4 || d->bytes[5] < 4 || hd.ep >= N ||
+    if (N == 0 || N > 0x7FFFFFFFull || d->bytes[0] != N * stride || d->bytes[1] != N * S0 * 4ull || d->bytes[3] != N * 4ull ||
+        d->bytes[2] == 0 || d->bytes[2] % (S1 * 4ull) != 0 || d->bytes[4] < 4 || d->bytes[4] % 4 != 0 || d->bytes[5] < 4 ||
+        (d->bytes[6] != 0) != (fat_stride != 0) || (fat_stride != 0 && d->bytes[6] != N * fat_stride) || hd.ep >= N ||
         hd.nb_layers == 0) {
         set_error("hnsw_snapshot_adopt: array sizes do not match the header");
         return HNSW_ERR_ARG;
@@ -2147,6 +2370,7 @@ int hnsw_snapshot_adopt(hnsw_index *h, hnsw_snapshot_desc *d) {
     v.fat_stride = ((uint64_t)hd.fat_stride_hi << 32) | hd.fat_stride_lo;
     h->dev.view = v;     // scalars now, pointers at commit
     h->dev.replica = true;
+    h->cosine = (hd.flags & 1u) != 0;
     return HNSW_OK;
 }
 
@@ -2223,6 +2447,8 @@ int hnsw_bench_search_threads(hnsw_index *h, const float *Q, uint64_t nq, uint32
     std::vector<std::thread> th;
     for (uint32_t t = 0; t < T; t++) th.emplace_back(work, t);
     while (ready.load() < T) std::this_thread::yield();
+    struct rusage ru0;
+    getrusage(RUSAGE_SELF, &ru0);
     t_start = clk::now();
     go.store(true, std::memory_order_release);
     for (auto &t : th) t.join();
@@ -2236,6 +2462,12 @@ int hnsw_bench_search_threads(hnsw_index *h, const float *Q, uint64_t nq, uint32
     std::sort(all.begin(), all.end());
     if (calls_out) *calls_out = all.size();
     if (wall_s) *wall_s = wall;
+    if (lat_us) {
+        struct rusage ru1;
+        getrusage(RUSAGE_SELF, &ru1);
+        lat_us[5] = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + 1e-6 * (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec);
+        lat_us[6] = (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + 1e-6 * (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec);
+    }
     if (lat_us && !all.empty()) {
         auto pct = [&](double p) { return (double)all[std::min(all.size() - 1, (size_t)(p * all.size()))]; };
         double sum = 0;

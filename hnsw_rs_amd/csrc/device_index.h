@@ -97,6 +97,9 @@ struct InsertArgs {
                                 // the records written are [0, min(*req_count, *req_fail_base))
     uint32_t req_cap;
     uint32_t emit_own;          // 1: no own-row writes, records in both directions (sharded build)
+    // optional (null otherwise): what the insertion searches read, summed over the launch -- [0] vector rows
+    // (distance evaluations + staged rows), [1] adjacency rows, [2] the ids in them.  The build's algorithmic bytes.
+    unsigned long long *counters;
 };
 
 // An edge record of the on-device connect, made to be radix-sorted: records of one adjacency row

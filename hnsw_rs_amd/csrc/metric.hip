@@ -5,7 +5,8 @@
 // arithmetic unchanged.  Host and device normalise with the same operations in the same order: the sum of
 // squares is one left-to-right f32 chain (no FMA), the square root and the divisions are the correctly
 // rounded forms, so a query normalised here equals the same vector normalised on the host bit for bit.
-// A zero vector has no direction: 0 / 0 = NaN, which the search reports as HNSW_ERR_NAN_INPUT.
+// A vector without a direction (zero, or a norm outside f32's range) becomes NaN, which the search reports as
+// HNSW_ERR_NAN_INPUT.
 #include <hip/hip_runtime.h>
 
 #include "device_index.h"
@@ -21,7 +22,10 @@ __global__ void __launch_bounds__(64) hx_normalise_rows_kernel(float *rows, uint
         const float t = x[e] * x[e];
         s += t;
     }
-    const float nrm = __builtin_sqrtf(s);
+    float nrm = __builtin_sqrtf(s);
+    // no direction (zero, or a sum of squares outside f32's range): the row becomes NaN, which the search reports as
+    // HNSW_ERR_NAN_INPUT -- an overflowed norm would otherwise turn the query into an all-zero vector silently
+    if (!(nrm > 0.0f) || nrm == __builtin_inff()) nrm = __builtin_nanf("");
     for (uint32_t e = 0; e < d; e++) x[e] = x[e] / nrm;
 }
 

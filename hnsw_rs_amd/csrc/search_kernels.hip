@@ -1956,6 +1956,9 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
     const bool first = (LPC == 1) || (h == 0);
     int32_t status = HNSW_OK;
     uint32_t n_vis = 0;
+    // what this point's insertion reads (wave-uniform; summed into a.counters at the end): vector rows
+    // (distance evaluations + staged rows), adjacency rows and the ids in them -- the build's algorithmic bytes
+    uint32_t c_rows = 1, c_adj = 0, c_ids = 0;
 
     const uint32_t level = min((uint32_t)a.levels[p], v.nb_layers - 1);
     const uint32_t m = a.m, ef_cons = max(1u, a.ef_cons);
@@ -1987,6 +1990,7 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
         const u64 fm = __ballot(fresh && first);
         if (visit) n_vis += (uint32_t)__popcll(fm);  // what the table really holds
         if (fm == 0) return;
+        c_rows += (uint32_t)__popcll(fm);
         const float dist = dist_build<KIND, DS, true>(v, id, fresh, h, yq, coop_ids, coop_img, lane);
         u64 key = KEY_INVALID;
         bool nan = false;
@@ -2044,12 +2048,14 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
             const uint32_t cid = take(cpos);
             const uint32_t *row = row_of(cid);
             if (row == nullptr) break;
+            c_adj++;
             if (two) {
                 const int cpos2 = wl.first_unexpanded(lane);
                 const uint32_t *row2 = nullptr;
                 if (cpos2 >= 0) {
                     row2 = row_of(take(cpos2));
                     if (row2 == nullptr) break;
+                    c_adj++;
                 }
                 const bool upper = lane >= 32;
                 const uint32_t slot = (uint32_t)lane & 31u;
@@ -2057,6 +2063,7 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
                 if (slot < S && (!upper || row2 != nullptr)) nb = (upper ? row2 : row)[slot];
                 const bool valid = nb != HX_EMPTY_SLOT && !(nb & HX_OVF_FLAG) && nb != p;
                 const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
+                c_ids += cnt;
                 if (cnt == 0) continue;
                 if (n_vis + cnt > vis_limit) {
                     status = HNSW_ERR_OVERFLOW;
@@ -2073,6 +2080,7 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
                 // to the stride when they are scattered); a flagged id is skipped
                 const bool valid = nb != HX_EMPTY_SLOT && !(nb & HX_OVF_FLAG) && nb != p;
                 const uint32_t cnt = (uint32_t)__popcll(__ballot(valid && first));
+                c_ids += cnt;
                 if (cnt == 0) continue;
                 if (n_vis + cnt > vis_limit) {
                     status = HNSW_ERR_OVERFLOW;
@@ -2153,6 +2161,7 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
                     const uint32_t cdb = (uint32_t)__shfl((int)my_db, src);
                     const bool act = __shfl(open ? 1 : 0, src) != 0;
                     if (__ballot(act) == 0) continue;
+                    c_rows += (uint32_t)__popcll(__ballot(act && first));
                     const float dist = dist_build<KIND, DS, true>(v, cid, act, h, yqe, coop_ids, coop_img, lane);
                     bool rej = false;
                     if (act && first) {
@@ -2190,6 +2199,7 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
                 const uint32_t new_end = min(n_c, win_end + 64u);
                 for (uint32_t k2 = 0; k2 < ns && status == HNSW_OK; k2++) {  // catch up: the new part against the selected
                     const uint32_t sid2 = (uint32_t)selk[k2];
+                    c_rows++;
                     stage_row<KIND>(v, sid2, yqe, lane);
                     sweep(sid2, win_end, new_end);
                 }
@@ -2211,6 +2221,7 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
             wave_fence();
             if (ns >= m || (cursor >= win_end && win_end >= n_c)) continue;  // nothing left to decide
             const uint32_t sid = (uint32_t)sk_sel;
+            c_rows++;
             stage_row<KIND>(v, sid, yqe, lane);
             sweep(sid, cursor, win_end);
             if (__ballot(status != HNSW_OK)) status = HNSW_ERR_NAN_INPUT;
@@ -2317,6 +2328,11 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
         }
     }
     if (lane == 0) a.out_status[b] = status;
+    if (a.counters != nullptr && lane == 0) {
+        atomicAdd(a.counters + 0, (unsigned long long)c_rows);
+        atomicAdd(a.counters + 1, (unsigned long long)c_adj);
+        atomicAdd(a.counters + 2, (unsigned long long)c_ids);
+    }
 }
 
 // rows[row_index[i]] = data[i] for whole adjacency rows of S slots (dirty rows after a build batch)

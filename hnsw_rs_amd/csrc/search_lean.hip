@@ -819,8 +819,21 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
 #endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef HX_STAMPS
+                // (diagnostic build) what is left of the row round trip once the claims are done, then the chain alone
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const unsigned long long g0 = __builtin_readcyclecounter();  // (not stamp_now: that would wait for the rows)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const unsigned long long g1 = stamp_now();
+                dbg_acc[2] += g1 - g0;
+#endif
                 const float s = chain_sum<DS>(w, qv);
                 dist = __builtin_sqrtf(s);
+#ifdef HX_STAMPS
+                asm volatile("" ::"v"(dist) : "memory");
+                dbg_acc[3] += stamp_now() - g1;
+#endif
             }
             const bool want = upper ? want_pre : fresh;
             const u64 vmask = __ballot(valid), fmask = __ballot(fresh);
@@ -841,7 +854,6 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
             STAMP(f2);
             STAMP_ADD(1, f1, f2);
             STAMP(f3);
-            STAMP_ADD(3, f2, f3);
 #ifdef HX_STAMPS
             {
                 const uint32_t mm = (uint32_t)__popcll(__ballot(!upper && key < lst.last_key));

@@ -167,15 +167,18 @@ class PipelinedShardedSearch:
 
     ids and dists travel in ONE gather (a [G, 2, s, n] int32 buffer: ids, then the distance bits).
     Every step has its own statistics buffer; the number of queries of a group that did not finish with
-    status 0 (visited table overflow, NaN) travels back with the results -- a failed query never comes back
-    as a row of padding ids.  Failure is COLLECTIVE: only the root sees the words, so it never raises in the
-    middle of the agreed sequence of collectives (the other ranks would enter the next scatter / gather and
-    wait for the RCCL timeout); it records the first failing group (`failure`, readable any time on the
-    root), every rank keeps issuing the same collectives, and `finish()` -- which every rank calls -- ends
-    with a one-word broadcast from the root after which EVERY rank raises.
-    `submit(Q_root, g)` enqueues a group of g steps; `results(k)` (root only) returns the group's
-    outputs, valid until `depth` more groups have been submitted; `finish()` drains everything and raises
-    on every rank if any query of any group failed.  depth >= 2: a group's failure word is read one submit
+    status 0 (visited table overflow, NaN) travels back with the results, one word per rank and group, and
+    `results` reads a group's word before it hands out any of its rows: the rows of a group with failed queries are
+    REFUSED (`FailedGroup`, carrying the per-rank counts; `with_status=True` returns rows and counts instead) -- a
+    failed query never comes back unnoticed as a row of padding ids.  Every failing group is recorded (`failures`:
+    group -> per-rank counts; `failure` = the first), on the root.  Failure is COLLECTIVE: only the root sees the
+    words, so the library itself never raises in the middle of the agreed sequence of collectives (the other ranks
+    would enter the next scatter / gather and wait for the RCCL timeout): every rank keeps issuing the same
+    collectives, and `finish()` -- which every rank calls, also a root that caught a FailedGroup -- ends with a
+    one-word broadcast from the root after which EVERY rank raises.
+    `submit(Q_root, g)` enqueues a group of g steps; `results(k, j)` (root only) returns step j of group k,
+    valid from the submit after the group's own until `depth` more groups have been submitted; `finish()` drains
+    everything and raises on every rank if any query of any group failed.  depth >= 2: a group's failure word is read one submit
     after its gather was enqueued, from a buffer the next gather of the same slot overwrites.
 
     search_step(q [s, dim], ids_out [s, n] int32, dist_bits_out [s, n] int32, stats_out [s, 4] int32, lane)
@@ -212,6 +215,8 @@ class PipelinedShardedSearch:
         self.gathered = []   # groups gathered but not yet checked: (group index, steps)
         self.n_groups = 0
         self.failure = None  # root: (group index, failed queries per rank) of the first failing group
+        self.failures = {}   # root: every failing group -> failed queries per rank
+        self.words = {}      # root: the failure words read so far (the last few groups)
 
     @staticmethod
     def from_index(index, dim, n, ef, shard, device, **kw):
@@ -264,18 +269,30 @@ class PipelinedShardedSearch:
             L.record(L.comm, self.ev_g[b])
         self.gathered.append((k, g))
 
+    def _word(self, k):
+        """root: failed queries per rank of group k, read once through the pinned buffer of its slot (valid until
+        `depth` more groups have been gathered, like the group's rows)"""
+        if k in self.words:
+            return self.words[k]
+        slot = k % self.depth
+        if self.ev_c[slot] is not None:
+            self.ev_c[slot].synchronize()  # the word has landed; nothing else is waited for
+        bad = [int(x) for x in self.bad_host[slot].tolist()]
+        self.words[k] = bad
+        self.words.pop(k - 4 * self.depth, None)
+        if any(bad):
+            self.failures[k] = bad
+            if self.failure is None:
+                self.failure = (k, bad)
+        return bad
+
     def _check(self, keep_last=0):
-        """root: note the first gathered group that reports failed queries (one word per rank and group).
-        Nothing is raised here: see the class comment."""
+        """root: read the word of every gathered group before its slot is reused.  Nothing is raised here: see
+        the class comment."""
         while len(self.gathered) > keep_last:
             k, g = self.gathered.pop(0)
-            if self.rank != self.root:
-                continue
-            if self.ev_c[k % self.depth] is not None:
-                self.ev_c[k % self.depth].synchronize()  # the word has landed; nothing else is waited for
-            bad = self.bad_host[k % self.depth].clone()
-            if int(bad.sum()) != 0 and self.failure is None:
-                self.failure = (k, bad.tolist())
+            if self.rank == self.root:
+                self._word(k)
 
     def submit(self, Q_root, g):
         """Q_root: [g, world * shard, dim] on the root (None elsewhere), 1 <= g <= group_steps."""
@@ -308,7 +325,29 @@ class PipelinedShardedSearch:
             raise RuntimeError("group %d:%s did not finish with status 0 (visited table overflow or NaN); "
                                "re-run them through hnsw_search_batch" % (int(w[1]), detail))
 
-    def results(self, k, j):
-        """(ids [W*s, n] int32, dists [W*s, n] f32) of step j of group k, on the root"""
+    def results(self, k, j, with_status=False):
+        """(ids [W*s, n] int32, dists [W*s, n] f32) of step j of group k, on the root.  The group's failure word is
+        read first: a group with failed queries raises FailedGroup instead of handing out rows that may be padding
+        (the caller still calls finish(), which is collective); with_status=True returns (ids, dists, failed
+        queries per rank) and never raises."""
+        if self.pending is not None and self.pending[0] == k:
+            raise ValueError("group %d has not been gathered yet: submit the next group or call finish() first" % k)
+        if not (self.n_groups - self.depth <= k < self.n_groups) and k not in self.words:
+            raise ValueError("group %d is no longer held (%d groups submitted, depth %d)" % (k, self.n_groups, self.depth))
+        bad = self._word(k)
         o = self.out[k % self.depth][:, j]
-        return o[:, 0].reshape(-1, self.n), o[:, 1].reshape(-1, self.n).view(torch.float32)
+        rows = (o[:, 0].reshape(-1, self.n), o[:, 1].reshape(-1, self.n).view(torch.float32))
+        if with_status:
+            return rows + (bad,)
+        if any(bad):
+            raise FailedGroup(k, bad)
+        return rows
+
+
+class FailedGroup(RuntimeError):
+    """results() of a group in which queries did not finish with status 0; `.bad` = failed queries per rank"""
+
+    def __init__(self, k, bad):
+        super().__init__("group %d: %s queries per rank did not finish with status 0 (visited table overflow or NaN); "
+                         "its rows are not handed out -- re-run them through hnsw_search_batch" % (k, bad))
+        self.group, self.bad = k, bad

@@ -384,7 +384,7 @@ class HNSW:
     def search_threads(self, Q, n, ef, threads, seconds):
         """The reference's call pattern as a load (hnsw_bench_search_threads): `threads` host threads, each blocked in
         its own one-query hnsw_search call.  -> (ids [nq, n], counts [nq], calls, wall seconds,
-        {p50, p90, p99, max, mean} latency in us)"""
+        {p50, p90, p99, max, mean} latency in us + cpu_user_s / cpu_sys_s of the process over the run)"""
         Q = np.ascontiguousarray(Q, dtype=np.float32)
         if Q.ndim != 2 or Q.shape[1] != self.dim:
             raise HnswError(_lib.ERR_BAD_DIM, "queries must be nq x %d" % self.dim)
@@ -392,10 +392,10 @@ class HNSW:
         ids = np.full((nq, max(n, 1)), _lib.UINT32_MAX, dtype=np.uint32)
         counts = np.zeros(nq, dtype=np.uint32)
         calls, wall = C.c_uint64(), C.c_double()
-        lat = (C.c_double * 5)()
+        lat = (C.c_double * 7)()
         check(self._L.hnsw_bench_search_threads(self._h, _p(Q, _f32p), nq, n, ef, int(threads), float(seconds),
                                                 _p(ids, _u32p), _p(counts, _u32p), C.byref(calls), C.byref(wall), lat))
-        return ids[:, :n], counts, calls.value, wall.value, dict(zip(("p50", "p90", "p99", "max", "mean"), list(lat)))
+        return ids[:, :n], counts, calls.value, wall.value, dict(zip(("p50", "p90", "p99", "max", "mean", "cpu_user_s", "cpu_sys_s"), list(lat)))
 
     # ---- replication over the GPUs of a node ------------------------------------
     @staticmethod

@@ -275,7 +275,12 @@ int hnsw_set_option(hnsw_index *h, const char *key, int64_t value);
 /* counters of the handle: "uploads" (whole-snapshot uploads), "point_patches" (insert_vec calls that patched the
  * live snapshot), "patch_fallbacks" (those that could not: the next search uploads), "coalesced_batches" /
  * "coalesced_queries" / "coalesced_max_batch" (launches made for hnsw_search calls, the calls they answered, the
- * largest batch) */
+ * largest batch), "coalesce_ns_window" / "_turn" / "_gpu" / "_handout" (where the batch leaders' time went);
+ * the on-device builds of the handle, summed: "build_points", "build_batches", "build_rows_read" (vector rows the
+ * insertion searches and the heuristic read: distance evaluations + staged rows), "build_adj_rows" / "build_adj_ids"
+ * (adjacency rows read and the ids in them), "build_records" / "build_removals" (edge records filed, reverse edges
+ * dropped), "build_insert_kernel_us" (hx_insert_kernel, HIP events), "build_insert_phase_us" / "build_connect_us"
+ * (host clock: phase 1 with its copies, sort + connect + remove) */
 int hnsw_get_stat(const hnsw_index *h, const char *key, uint64_t *out);
 
 /* ---- replication of the HBM snapshot over the GPUs of a node ----------------------------------- */
@@ -314,7 +319,8 @@ int hnsw_draw_levels(uint32_t m, uint64_t n, uint8_t *out);
  * (ann_by_vector(&self, ...), template.rs:306-335, one query per call).  Thread t answers queries t, t + T, ... of
  * Q (nq x dim) again and again until `seconds` have passed and every query has been answered at least once.
  * ids (nq x n) / counts (nq, may be NULL) receive each query's last answer, *calls the number of completed calls,
- * *wall_s the elapsed time, lat_us[5] = {p50, p90, p99, max, mean} of the per-call latency in microseconds. */
+ * *wall_s the elapsed time, lat_us[7] = {p50, p90, p99, max, mean} of the per-call latency in microseconds, then the
+ * process's user and system CPU seconds over the run. */
 int hnsw_bench_search_threads(hnsw_index *h, const float *Q, uint64_t nq, uint32_t n, uint32_t ef, uint32_t threads,
                               double seconds, uint32_t *ids, uint32_t *counts, uint64_t *calls, double *wall_s,
                               double *lat_us);

@@ -26,7 +26,7 @@ qs = H.synth_rows(0, 0x5EED0002, 0, 10240, d, 16)
 print("index %d x %dd %s built in %.1fs" % (N, d, kind_name, time.time() - t0), flush=True)
 ref_ids, _, ref_c, _ = index.search_batch(qs, 10, ef)
 
-for window, depth in ((0, 2), (30, 2), (30, 4), (30, 8), (30, 64), (100, 64)):
+for window, depth in ((30, 2), (30, 3), (60, 2)):
     index.set_option("coalesce_us", window)
     index.set_option("coalesce_depth", depth)
     for T in (1, 16, 64, 256, 1024):
@@ -39,6 +39,7 @@ for window, depth in ((0, 2), (30, 2), (30, 4), (30, 8), (30, 64), (100, 64)):
         nb, nq = dl[0], dl[1]
         same = bool(np.array_equal(ids, ref_ids))
         ph = " leader us/batch: window %.0f turn %.0f gpu %.0f handout %.0f" % tuple(x / 1e3 / nb for x in dl[2:]) if nb else ""
+        ph += "  cpu %.1f user + %.1f sys cores" % (lat["cpu_user_s"] / wall, lat["cpu_sys_s"] / wall)
         print("coalesce_us %3d depth %d  T %4d: %9.0f q/s  p50 %6.0f us  p99 %6.0f us  mean batch %6.1f  identical %s%s" % (
             window, depth, T, calls / wall, lat["p50"], lat["p99"], (nq / nb) if nb else 1.0, same, ph), flush=True)
 

@@ -4,19 +4,11 @@
 //! -- with the same names and signatures, implemented on the C ABI of libhnsw_mi355x.so
 //! (include/hnsw_mi355x.h).  Source only: the build image has no rustc, so this crate has never been
 //! compiled (tests/test_shim_surface.py checks the public surface against the reference's by name).
-//! The files are named after what they hold and mounted at the reference's module paths here.
-//! Not carried over: `hnsw::disk` (private dead code in the reference), `helpers::get_progress_bar`
-//! (returns an indicatif type), `helpers::data::load_bf_data` (reads the author's home directory).
+//! The files sit where the reference's modules sit (`params.rs`, `template.rs`, `helpers/args.rs`,
+//! `helpers/glove.rs`).  Not carried over: `hnsw::disk` (private dead code in the reference),
+//! `helpers::get_progress_bar` (returns an indicatif type), `helpers::data` (`split` has no caller in the
+//! reference, `load_bf_data` reads the author's home directory).
 pub mod ffi;
-#[path = "gpu_params.rs"]
+pub mod helpers;
 pub mod params;
-#[path = "gpu_index.rs"]
 pub mod template;
-pub mod helpers {
-    #[path = "../cli_args.rs"]
-    pub mod args;
-    #[path = "../glove_text.rs"]
-    pub mod glove;
-    #[path = "../data_split.rs"]
-    pub mod data;
-}

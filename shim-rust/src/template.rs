@@ -51,13 +51,18 @@ impl<'a> Graph<'a> {
         out.into_iter()
     }
     pub fn neighbors(&self, node: NodeID) -> Result<std::collections::HashSet<NodeID>, String> {
-        let mut buf = vec![0u32; 4096];
+        // a row has no fixed length (degree may exceed the layer's cap, graph.rs:37-52 never checks it): ask for the
+        // degree first, then for exactly that many ids
         let mut deg = 0u32;
-        let rc = unsafe {
-            hnsw_neighbors(self.index.handle, self.level as u32, node, buf.as_mut_ptr(), 4096, &mut deg)
-        };
+        let rc = unsafe { hnsw_neighbors(self.index.handle, self.level as u32, node, ptr::null_mut(), 0, &mut deg) };
         if rc != HNSW_OK {
             return Err(last_error()); // GraphError::NodeNotInGraph
+        }
+        let mut buf = vec![0u32; (deg as usize).max(1)];
+        let cap = buf.len() as u32;
+        let rc = unsafe { hnsw_neighbors(self.index.handle, self.level as u32, node, buf.as_mut_ptr(), cap, &mut deg) };
+        if rc != HNSW_OK {
+            return Err(last_error());
         }
         buf.truncate(deg as usize);
         Ok(buf.into_iter().collect())
@@ -77,21 +82,13 @@ impl HNSW {
     fn refresh_params(&mut self) {
         let mut p = HnswParams::default();
         unsafe { hnsw_get_params(self.handle, &mut p) };
-        self.params = Params {
-            ep: p.ep,
-            m: p.m as usize,
-            mmax: p.mmax as usize,
-            mmax0: p.mmax0 as usize,
-            ml: p.ml,
-            ef_cons: p.ef_cons as usize,
-            dim: p.dim as usize,
-        };
+        self.params = Params::from(&p);
     }
 
     fn from_handle(handle: *mut HnswIndex) -> Self {
         let mut s = HNSW {
             handle,
-            params: Params { ep: 0, m: 0, mmax: 0, mmax0: 0, ml: 0.0, ef_cons: 0, dim: 0 },
+            params: Params::unset(),
         };
         s.refresh_params();
         s

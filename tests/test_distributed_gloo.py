@@ -102,14 +102,24 @@ def _pipe_worker(rank, world, port, outfile, inject_failure):
                                   lanes=InlineLanes())
     steps = 7  # groups of 2, 2, 2 and 1 steps: the last group is a partial one
     Q = torch.from_numpy(rand_vectors(steps * world * shard, d, 2)).view(steps, world * shard, d)
-    got, failed = {}, ""
+    from hnsw_rs_amd.distributed import FailedGroup
+    got, failed, refused = {}, "", []
     try:
         i = 0
         while i < steps:
             g = min(G, steps - i)
             kk = pipe.submit(Q[i:i + g].contiguous() if rank == 0 else None, g)
-            if rank == 0 and kk >= 1:  # results of the group before stay valid until `depth` more submits
-                pass
+            if rank == 0 and kk >= 1:
+                # a root that consumes results BETWEEN submits: the group before is gathered by now.  The rows of a
+                # failed group are refused (never padding ids without a signal), the other groups' rows are handed
+                # out, and the root stays in the sequence of collectives either way
+                try:
+                    ids, dists = pipe.results(kk - 1, 0)
+                    w_ids, w_d, _, _ = orc.search_batch(Q[i - G].numpy(), k, ef)
+                    assert np.array_equal(ids.numpy().astype(np.uint32), w_ids) and np.array_equal(dists.numpy(), w_d)
+                except FailedGroup as e:
+                    refused.append((e.group, e.bad))
+                    assert pipe.results(kk - 1, 0, with_status=True)[2] == e.bad
             i += g
         pipe.finish()
     except RuntimeError as e:
@@ -123,9 +133,10 @@ def _pipe_worker(rank, world, port, outfile, inject_failure):
                     ids, dists = pipe.results(kk, j)
                     w_ids, w_d, _, _ = orc.search_batch(Q[first + j].numpy(), k, ef)
                     ok &= np.array_equal(ids.numpy().astype(np.uint32), w_ids) and np.array_equal(dists.numpy(), w_d)
-            ok &= failed == ""
+            ok &= failed == "" and refused == [] and pipe.failures == {}
         else:
             ok = "group 0:" in failed and "did not finish with status 0" in failed and pipe.failure == (0, [0, 1])
+            ok &= refused == [(0, [0, 1])] and pipe.failures == {0: [0, 1]}
         open(outfile, "w").write("ok" if ok else "mismatch: " + failed)
     else:
         # the failure is collective: the other rank issued every collective of the sequence (or this

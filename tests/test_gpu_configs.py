@@ -359,9 +359,21 @@ def test_cosine_option_is_l2_on_unit_vectors(kind):
     cos.insert_bulk(vs, 1, False, levels=lv)  # one build thread: two builds of the same rows give the same graph
     ref = H.HNSW.new(m, 32, d, kind).insert_bulk(_unit_rows(vs), 1, False, levels=lv)
     uq = _unit_rows(qs)
+    # the pin: the ORACLE (the reference's L2 arithmetic) over rows and queries normalised by the restated arithmetic
+    # (numpy float32, one left-to-right sum of squares: tests/test_host_build.py::_unit_rows), holding the same graph
+    orc = oracle_from_product(cos, _unit_rows(vs), lv)
     for ef in (16, 64):
-        assert_search_equal(cos.search_batch(qs, 10, ef), ref.search_batch(uq, 10, ef), "cosine ef=%d" % ef)
-    assert np.array_equal(cos.brute_force(qs[:8], 10)[0], ref.brute_force(uq[:8], 10)[0])
+        got = cos.search_batch(qs, 10, ef)
+        assert_search_equal(got, orc.search_batch(uq, 10, ef), "cosine vs oracle on unit rows, ef=%d" % ef)
+        assert_search_equal(got, ref.search_batch(uq, 10, ef), "cosine ef=%d" % ef)
+    for i in range(4):  # the one-query entry (coalescer path) normalises too
+        assert cos.ann_by_vector(qs[i], 10, 64) == [int(x) for x in orc.ann_by_vector(uq[i], 10, 64)]
+    o_bf = orc.brute_force(uq[:8], 10)
+    c_bf = cos.brute_force(qs[:8], 10)
+    assert np.array_equal(c_bf[0], o_bf[0]) and np.array_equal(c_bf[1].view(np.uint32), o_bf[1].view(np.uint32))
+    assert np.array_equal(c_bf[0], ref.brute_force(uq[:8], 10)[0])
+    # a clone keeps the metric: it normalises its queries like the original
+    assert_search_equal(cos.clone().search_batch(qs, 10, 64), orc.search_batch(uq, 10, 64), "clone of a cosine index")
     if kind == H.VEC_F32:
         # device-resident queries go through the same normalisation
         import torch
@@ -373,8 +385,10 @@ def test_cosine_option_is_l2_on_unit_vectors(kind):
         st = torch.empty((128, 4), dtype=torch.int32, device=dev)
         cos.search_batch_device(dQ.data_ptr(), 128, 10, 64, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), st.data_ptr(), 0)
         cos.search_batch_device_finish(dQ.data_ptr(), 128, 10, 64, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), st.data_ptr(), 0)
-        w = ref.search_batch(uq, 10, 64)
-        assert np.array_equal(ids.cpu().numpy().view(np.uint32), w[0]) and np.array_equal(dd.cpu().numpy(), w[1])
+        w = orc.search_batch(uq, 10, 64)  # the device-pointer entry against the oracle
+        assert np.array_equal(ids.cpu().numpy().view(np.uint32), w[0])
+        assert np.array_equal(dd.cpu().numpy().view(np.uint32), w[1].view(np.uint32))
+        assert np.array_equal(st.cpu().numpy()[:, :3].astype(np.int64), np.asarray(w[3])[:, :3].astype(np.int64))
         assert torch.equal(dQ.cpu(), torch.from_numpy(qs))  # the caller's queries are left as they were
         # the exact top-10 by cosine similarity (float64) is what the exhaustive scan returns
         sims = (_unit_rows(vs).astype(np.float64) @ uq[:8].astype(np.float64).T).T

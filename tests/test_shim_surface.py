@@ -29,14 +29,18 @@ def read(name):
 
 
 def module_file(path):
-    """source file of shim module `a::b::c` (crate-relative), following the #[path] mounts of lib.rs"""
-    lib = read("lib.rs")
-    leaf = path[-1]
-    m = re.search(r'#\[path\s*=\s*"([^"]+)"\]\s*pub mod %s;' % re.escape(leaf), lib)
-    if m:
-        return os.path.basename(m.group(1))
-    assert re.search(r"pub mod %s;" % re.escape(leaf), lib), "module %s is not declared" % "::".join(path)
-    return leaf + ".rs"
+    """source file of shim module `a::b::c` (crate-relative): the standard layout -- every module is declared
+    `pub mod x;` by its parent (lib.rs, or the parent's mod.rs) and lives in x.rs or x/mod.rs beside it"""
+    rel, decl = "", "lib.rs"
+    for mod in path:
+        assert re.search(r"pub mod %s;" % re.escape(mod), read(decl)), "module %s is not declared in %s" % ("::".join(path), decl)
+        flat, nested = os.path.join(rel, mod + ".rs"), os.path.join(rel, mod, "mod.rs")
+        if os.path.exists(os.path.join(SHIM, nested)):
+            rel, decl = os.path.join(rel, mod), nested
+        else:
+            assert os.path.exists(os.path.join(SHIM, flat)), "%s not found" % flat
+            decl = flat
+    return decl
 
 
 def pub_fns(src):
@@ -54,9 +58,7 @@ def test_every_caller_import_resolves():
     for imp in CALLER_IMPORTS:
         parts = imp.split("::")[1:]
         item, mods = parts[-1], parts[:-1]
-        for depth, mod in enumerate(mods):
-            assert re.search(r"pub mod %s\b" % mod, lib), "%s: module `%s` missing from lib.rs" % (imp, mod)
-        src = read(module_file(mods))
+        src = read(module_file(mods))  # (asserts that every module on the path is declared by its parent)
         assert re.search(r"pub (fn|struct|type) %s\b" % item, src), "%s: `%s` not public in %s" % (
             imp, item, module_file(mods))
 
