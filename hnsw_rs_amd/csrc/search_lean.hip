@@ -33,6 +33,7 @@
 // Float fidelity: -ffp-contract=off; the sum is FullVec's single left-to-right chain; sqrt is the
 // correctly rounded one.
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "device_index.h"
@@ -66,6 +67,11 @@ struct LeanArgs {
     hnsw_query_stats *out_stats;
     uint32_t n_points, ep, nb_layers, S0, S1, ef, n, slots_log2;
     unsigned long long *dbg;  // diagnostic builds only (HX_STAMPS)
+    // second level of the visited set (eight-register lists, ef > 320): 1 << spill_log2 words of HBM per launched
+    // query, or null
+    uint32_t *spill_tab;
+    uint32_t spill_log2;
+    uint32_t lds_limit;  // ids the LDS level takes before it is closed; 0 = 75 % of its slots (tests lower it)
 };
 
 // Diagnostic build only (make stamps): per-phase cycle sums, written to a side buffer nothing else reads.
@@ -164,6 +170,89 @@ struct Visited {
         for (uint32_t s = lane; s < (nslots >> 2); s += 64)
             reinterpret_cast<uint4 *>(tab)[s] = make_uint4(HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT);
         lds_fence();
+    }
+
+    // ---- second level (round 4; the eight-register kernels, 320 < ef <= 512) ----------------------------------
+    // A 64-KiB table leaves two waves per CU, i.e. a batch of 1024 runs in two rounds (4.7 us per expansion
+    // against 2.8 at ef 320).  The LDS table stays at 32 KiB instead; once it holds its limit it is CLOSED (looked
+    // at, never written again) and the ids that arrive afterwards go to a table in HBM that only the queries
+    // which get that far ever touch: one slot per id, linear probing, agent-scope loads and a compare-and-swap in
+    // L2 (the scheme of hx_search_spill_kernel, search_kernels.hip).  An id is in the set iff it is in either
+    // level, and an id is only ever inserted after both levels were found not to hold it: the set -- and with it
+    // the fresh sets, the counters and the result -- is the one-level table's (IntSet, results.rs:101-103).
+    uint32_t *gtab = nullptr;
+    uint32_t gshift = 0, gmask = 0;
+    bool spill = false;  // wave-uniform: the LDS level is closed
+
+    __device__ __forceinline__ bool g_contains(uint32_t id) const {
+        uint32_t s = ((id * 0x9E3779B1u) >> gshift) & gmask;
+        while (true) {
+            const uint32_t cur = __hip_atomic_load(gtab + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == id) return true;
+            if (cur == HX_EMPTY_SLOT) return false;
+            s = (s + 1) & gmask;
+        }
+    }
+    // exact insert into the HBM level: HX_EMPTY_SLOT when id was absent (now inserted), id when it was there.
+    // The compare-and-swap IS the probe (it returns what the slot holds): one round trip per slot looked at.
+    __device__ __forceinline__ uint32_t g_claim(uint32_t id) const {
+        uint32_t s = ((id * 0x9E3779B1u) >> gshift) & gmask;
+        while (true) {
+            const uint32_t old = atomicCAS(gtab + s, HX_EMPTY_SLOT, id);
+            if (old == HX_EMPTY_SLOT) return HX_EMPTY_SLOT;
+            if (old == id) return id;
+            s = (s + 1) & gmask;  // taken by another id (possibly of this very pass): next slot
+        }
+    }
+    // close the LDS level: from here on new ids go to the HBM level, emptied now
+    __device__ __forceinline__ void open_second_level(int lane) {
+        const uint32_t nslots = gmask + 1;
+        for (uint32_t s = lane; s < (nslots >> 2); s += 64)
+            reinterpret_cast<uint4 *>(gtab)[s] = make_uint4(HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have reached L2 before the first probe
+        spill = true;
+    }
+    // look over both levels.  While the LDS level is open: 0..3 / 4 / 5 as look().  Closed: 4 = present in either
+    // level; 6 = absent from both (to be claimed in the HBM level later: the runner-up's lanes, which only look);
+    // 7 = was absent from both and has just been claimed in the HBM level -- the lanes with claim_now (the candidate's:
+    // they insert whatever is absent, and nothing else touches the set between their look and their claim, so
+    // claiming at the look is the same insert one HBM round trip earlier; a runner-up lane that does or does not see
+    // it yet is right either way, its own insert at its commit is exact).  probe == false: 4 (a lane without an id).
+    __device__ __forceinline__ uint32_t look2(uint32_t id, uint32_t b, bool probe, bool claim_now) const {
+        uint32_t t = look(id, b);
+        if (!spill) return t;
+        if (!probe) return 4u;
+        while (t == 5u) {  // a full bucket: the id may sit in a later one
+            b = (b + 1) & bmask;
+            t = look(id, b);
+        }
+        if (t == 4u) return 4u;
+        if (claim_now) return g_claim(id) == HX_EMPTY_SLOT ? 7u : 4u;
+        return g_contains(id) ? 4u : 6u;
+    }
+    __device__ __forceinline__ uint32_t claim2(uint32_t id, uint32_t b, uint32_t t) const {
+        uint32_t old = 0;
+        if (t < 4u)
+            old = atomicCAS(tab + 4 * b + t, HX_EMPTY_SLOT, id);
+        else if (t == 6u)
+            old = g_claim(id);
+        else if (t == 7u)
+            old = HX_EMPTY_SLOT;  // claimed at the look
+        return old;
+    }
+    __device__ __forceinline__ bool finish2(uint32_t id, uint32_t b, uint32_t t, bool pend, bool fresh) const {
+        while (__ballot(pend)) {
+            if (pend) {
+                if (t == 5u) b = (b + 1) & bmask;
+                t = look2(id, b, true, false);
+                const uint32_t old = claim2(id, b, t);
+                const bool won = old == HX_EMPTY_SLOT;
+                fresh |= won;
+                pend = (t != 4u) & !won;  // (a lost HBM claim means the id is there: the next look says 4)
+            }
+        }
+        return fresh;
     }
 };
 
@@ -548,6 +637,7 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
     // to a line, and summed by their owner lanes out of an LDS image (coop_rows.inc): no row registers, so the
     // query's 128 values still fit beside the stage ring
     constexpr bool COOP = coop_rows<HNSW_VEC_F32, DS>();
+    constexpr bool SPILLV = R >= 6;  // ef > 320: the visited set may continue in HBM (Visited::look2)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const uint32_t q = a.qsel ? a.qsel[blockIdx.x] : blockIdx.x;
@@ -720,7 +810,19 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
     if (status == HNSW_OK) {
         vis.bshift = 32 - (a.slots_log2 - 2);
         vis.bmask = (hslots >> 2) - 1;
-        const uint32_t vis_limit = hslots - (hslots >> 2);  // 75 % load at most
+        uint32_t lds_limit = hslots - (hslots >> 2);  // 75 % load at most
+        if constexpr (SPILLV) {
+            if (a.spill_tab != nullptr && a.lds_limit != 0) lds_limit = min(lds_limit, max(128u, a.lds_limit));
+        }
+        uint32_t vis_limit = lds_limit;
+        if constexpr (SPILLV) {
+            if (a.spill_tab != nullptr) {  // a second level in HBM takes what the LDS table cannot (Visited, above)
+                vis.gtab = a.spill_tab + ((size_t)blockIdx.x << a.spill_log2);
+                vis.gmask = (1u << a.spill_log2) - 1;
+                vis.gshift = 32 - a.spill_log2;
+                vis_limit = lds_limit + (1u << a.spill_log2) / 2;  // the HBM level at half load
+            }
+        }
         vis.clear(hslots, lane);
         vis.insert(cur, lane == 0);
         n_vis = 1;
@@ -737,6 +839,10 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
 
         while (true) {
             STAMP(f0);
+            if constexpr (SPILLV) {
+                // the LDS table has reached its limit (it may hold 64 more: one pass): closed from this pass on
+                if (HX_UNLIKELY(!vis.spill && vis.gtab != nullptr && n_vis + 64u > lds_limit)) vis.open_second_level(lane);
+            }
             int ppos = -1;
             uint32_t pid = HX_EMPTY_SLOT;
             uint32_t nb = HX_EMPTY_SLOT;
@@ -779,7 +885,11 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
             // look (p's real insert happens at its commit, after everything c inserted; a stale "absent"
             // merely evaluates a distance for nothing) ----
             const uint32_t vb = vis.home(nb);
-            const uint32_t vt0 = vis.look(nb, vb);
+            uint32_t vt0;
+            if constexpr (SPILLV)
+                vt0 = vis.look2(nb, vb, valid, valid && !upper);  // (6 / 7: absent from both levels, see Visited)
+            else
+                vt0 = vis.look(nb, vb);
             const uint32_t vt = valid ? vt0 : 4u;       // 0..3 claimable slot, 4 nothing to do, 5 bucket full
             // The rows are requested as soon as the look says "absent" -- for c's lanes that is exactly the
             // set that ends up inserted, barring the rare id that sits in a later bucket of a full home
@@ -798,10 +908,10 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
             if constexpr (COOP) {
                 // claims first (c's lanes), then one cooperative gather for c's fresh rows and the rows p's
                 // look called absent
-                const uint32_t old = vis.claim(nb, vb, ct);
+                const uint32_t old = SPILLV ? vis.claim2(nb, vb, ct) : vis.claim(nb, vb, ct);
                 fresh = old == HX_EMPTY_SLOT;
                 const bool pend = (ct != 4u) & !fresh;
-                if (HX_UNLIKELY(__ballot(pend) != 0)) fresh = vis.finish(nb, vb, ct, pend, fresh);
+                if (HX_UNLIKELY(__ballot(pend) != 0)) fresh = SPILLV ? vis.finish2(nb, vb, ct, pend, fresh) : vis.finish(nb, vb, ct, pend, fresh);
                 dist = dist_of(nb, upper ? want_pre : fresh);
             } else if (want_pre) {
                 const uint4 *src = reinterpret_cast<const uint4 *>(a.rows + (size_t)nb * DS);
@@ -809,11 +919,11 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
 #pragma unroll
                 for (int p = 0; p < DS / 4; p++) w[p] = src[p];
                 __builtin_amdgcn_sched_barrier(0);
-                const uint32_t old = vis.claim(nb, vb, ct);
+                const uint32_t old = SPILLV ? vis.claim2(nb, vb, ct) : vis.claim(nb, vb, ct);
                 fresh = old == HX_EMPTY_SLOT;
                 const bool pend = (ct != 4u) & !fresh;
                 if (HX_UNLIKELY(__ballot(pend) != 0)) {
-                    fresh = vis.finish(nb, vb, ct, pend, fresh);
+                    fresh = SPILLV ? vis.finish2(nb, vb, ct, pend, fresh) : vis.finish(nb, vb, ct, pend, fresh);
 #ifdef HX_STAMPS
                     dbg_acc[11]++;
 #endif
@@ -903,10 +1013,11 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
             // still empty nothing entered the bucket since and the id is absent; if it now holds this very
             // id, c's commit inserted it; anything else sends the lane through the full insert.
             const uint32_t pt = upper ? vt : 4u;
-            const uint32_t pold = vis.claim(nb, vb, pt);
+            const uint32_t pold = SPILLV ? vis.claim2(nb, vb, pt) : vis.claim(nb, vb, pt);  // (pt == 6: the HBM claim is exact by itself)
             bool pfresh = pold == HX_EMPTY_SLOT;
             const bool ppend = (pt == 5u) | ((pt < 4u) & !pfresh & (pold != nb));
-            if (HX_UNLIKELY(__ballot(ppend) != 0)) pfresh = vis.finish(nb, vb, pt == 5u ? 5u : 0u, ppend, pfresh);
+            if (HX_UNLIKELY(__ballot(ppend) != 0))
+                pfresh = SPILLV ? vis.finish2(nb, vb, pt == 5u ? 5u : 0u, ppend, pfresh) : vis.finish(nb, vb, pt == 5u ? 5u : 0u, ppend, pfresh);
             const uint32_t nf_p = (uint32_t)__popcll(__ballot(pfresh));
             sum_deg += cnt_p;
             n_vis += nf_p;
@@ -1337,8 +1448,32 @@ int launch_lean_q8(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
 }
 
 template <int DS, class LT, int CK = 4>
-int launch_lean_one(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
+int launch_lean_one(const LeanArgs &a_in, uint32_t nblocks, hipStream_t stream) {
     constexpr int R = LT::NR;
+    LeanArgs a = a_in;
+    // eight-register lists (320 < ef <= 512): the LDS table stays at 32 KiB -- four waves per CU, a batch of 1024 in
+    // one round -- and a second level in HBM (stream-ordered scratch, 128 KiB per query) takes the ids beyond it
+    struct Scratch {
+        void *p = nullptr;
+        hipStream_t st = nullptr;
+        ~Scratch() {
+            if (p) (void)hipFreeAsync(p, st);
+        }
+    } sp;
+    static const bool two_level = !(getenv("HNSW_MI355X_VISITED_2L") && atoi(getenv("HNSW_MI355X_VISITED_2L")) == 0);
+    if (R >= 6 && two_level && a.slots_log2 > 13) {
+        const uint32_t glog2 = std::max(15u, a.slots_log2 + 1);
+        sp.st = stream;
+        if (hipMallocAsync(&sp.p, ((size_t)nblocks << glog2) * 4, stream) != hipSuccess) {
+            (void)hipGetLastError();
+            sp.p = nullptr;  // no scratch: the one-level table serves (two waves per CU)
+        } else {
+            a.spill_tab = static_cast<uint32_t *>(sp.p);
+            a.spill_log2 = glog2;
+            a.slots_log2 = 13;
+            if (const char *e = getenv("HNSW_MI355X_VISITED_2L_LIMIT")) a.lds_limit = (uint32_t)atoi(e);  // (tests: close the LDS level early)
+        }
+    }
     const size_t lds = (4ull << a.slots_log2) + (64ull * R + 64) * 8 +
                        (coop_rows<HNSW_VEC_F32, DS>() ? HX_COOP_IMG_BYTES + 256 : 0);
     auto kern = hx_lean_f32_kernel<DS, LT, CK>;
@@ -1431,7 +1566,12 @@ int launch_lean(const DevView &v, const SearchArgs &s, uint32_t nblocks, uint32_
         return few ? launch_lean_one<128, LstHT, 4>(a, nblocks, stream) : launch_lean_one<128, LstHT, 2>(a, nblocks, stream);
     }
     if (a.ef <= 64) return launch_lean_one<100, Lst<1>>(a, nblocks, stream);
-    if (a.ef > 256) return launch_lean_one<100, Lst<8>>(a, nblocks, stream);
+    // 256 < ef <= 512: as many interleaved registers as the list needs (round 4: five to eight; every register costs
+    // each pick, mark and merge -- 2.1 us per expansion with four, 2.9 with eight at the same ef)
+    if (a.ef > 448) return launch_lean_one<100, Lst<8>>(a, nblocks, stream);
+    if (a.ef > 384) return launch_lean_one<100, Lst<7>>(a, nblocks, stream);
+    if (a.ef > 320) return launch_lean_one<100, Lst<6>>(a, nblocks, stream);
+    if (a.ef > 256) return launch_lean_one<100, Lst<5>>(a, nblocks, stream);
     if (a.ef > 128) return launch_lean_one<100, Lst<4>>(a, nblocks, stream);
     if (interleaved) return launch_lean_one<100, Lst<2>>(a, nblocks, stream);
     return launch_lean_one<100, LstHT>(a, nblocks, stream);

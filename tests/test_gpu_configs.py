@@ -35,7 +35,7 @@ def f32_100d():
     return device_built(24000, 100, 16, H.VEC_F32)
 
 
-@pytest.mark.parametrize("ef", [64, 68, 96, 128, 129, 192, 256, 257, 400, 512, 513])
+@pytest.mark.parametrize("ef", [64, 68, 96, 128, 129, 192, 256, 257, 320, 321, 384, 385, 400, 448, 449, 512, 513])
 def test_the_timed_f32_kernel(f32_100d, ef):
     """configs[1]: 100d f32, M = 16 -- the lean kernel with one list register (ef <= 64), head + tail (<= 128), four
     and eight interleaved registers (<= 256, <= 512), the generic kernel beyond"""
@@ -83,6 +83,48 @@ def test_upload_without_pinned_staging_memory():
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HNSW_MI355X_NO_PINNED="1"),
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "plain staging ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("limit", ["", "300", "2000"])
+def test_two_level_visited_set_of_the_eight_register_kernel(limit):
+    """320 < ef <= 512 at d = 100 f32 (round 4): the LDS visited table stays at 32 KiB and the ids beyond its limit
+    go to a second level in HBM (Visited::look2, search_lean.hip).  HNSW_MI355X_VISITED_2L_LIMIT closes the LDS
+    level after 300 / 2000 ids, so that every query crosses into the second level early / half way; results and
+    counters must be the one-level table's, i.e. the oracle's (IntSet, results.rs:101-103).  Also the retry with a
+    larger table when the second level fills up, and rows longer than the stride across the switch."""
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import hnsw_rs_amd as H\n"
+        "from oracle import oracle_py as O\n"
+        "from tests.util import oracle_from_product, assert_search_equal\n"
+        "n, d, m = 60000, 100, 16\n"
+        "vs = H.synth_rows(0, 0x5EED0001, 0, n, d); qs = H.synth_rows(0, 0x5EED0002, 0, 192, d)\n"
+        "lv = O.draw_levels(n, m, 7)\n"
+        "idx = H.HNSW.new(m, 32, d, H.VEC_F32); idx.insert_bulk_device(vs, 8, False, levels=lv)\n"
+        "orc = oracle_from_product(idx, vs, lv)\n"
+        "for ef in (321, 384, 448, 512):\n"
+        "    got = idx.search_batch(qs, 10, ef)\n"
+        "    assert_search_equal(got, orc.search_batch(qs, 10, ef, nthreads=8), 'two-level ef=%%d' %% ef)\n"
+        "    assert int(np.asarray(got[3])[:, 0].max()) > 2500  # (the searches do reach past the early limits)\n"
+        "assert_search_equal(idx.search_batch(qs[:64], 400, 512), orc.search_batch(qs[:64], 400, 512, nthreads=8), 'n=400')\n"
+        "# a hub with 3000 neighbours: its overflow rows are expanded in passes that straddle the switch\n"
+        "ids, offs, nbrs = idx.get_layer(0).csr()\n"
+        "rows = [set(nbrs[offs[i]:offs[i + 1]].tolist()) for i in range(len(ids))]\n"
+        "hub = int(orc.search_batch(qs[:1], 1, 64)[0][0, 0])\n"
+        "for x in range(0, 9000, 3):\n"
+        "    if x != hub: rows[hub].add(x); rows[x].add(hub)\n"
+        "flat = np.concatenate([np.array(sorted(r), dtype=np.uint32) for r in rows])\n"
+        "o2 = np.zeros(len(ids) + 1, dtype=np.uint64); o2[1:] = np.cumsum([len(r) for r in rows])\n"
+        "idx.import_layer(0, ids, o2, flat)\n"
+        "orc2 = oracle_from_product(idx, vs, lv)\n"
+        "for ef in (400, 512):\n"
+        "    assert_search_equal(idx.search_batch(qs, 10, ef), orc2.search_batch(qs, 10, ef, nthreads=8), 'hub ef=%%d' %% ef)\n"
+        "print('two-level ok')\n" % ROOT)
+    env = dict(os.environ)
+    if limit:
+        env["HNSW_MI355X_VISITED_2L_LIMIT"] = limit
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "two-level ok" in out.stdout, out.stdout + out.stderr
 
 
 @pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])

@@ -17,7 +17,7 @@ for kind in (H.VEC_F32, H.VEC_QUANT8):
         orc = oracle_from_product(idx, vs, lv)
         for inline in ((1, 0) if kind == H.VEC_QUANT8 else (0,)):
             idx.set_option("inline_rows", inline)
-            for ef in (1, 3, 10, 33, 64, 65, 100, 128, 129, 200, 300):
+            for ef in (1, 3, 10, 33, 64, 65, 100, 128, 129, 200, 300, 321, 400, 512):
                 t = time.time()
                 g_ids, g_d, g_c, g_st = idx.search_batch(qs, 10, ef)
                 o_ids, o_d, o_c, o_st = orc.search_batch(qs, 10, ef, nthreads=16)
