@@ -442,6 +442,41 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
                                             "ms_per_step": round(el64 / 50 * 1e3, 5), "kernel_ms": round(ms64, 5),
                                             "hbm_frac_algorithmic": round(float(bq64.mean() * B) / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                             "recall_at_%d" % n: recall_by_ef[64]}
+    # ---- the roof that binds a 1024-query batch: one query's own dependent chain.  Measured live: the same kernel
+    # over 64 queries (a wave alone on its CU -- nothing to share the address path, the LDS or the issue slots
+    # with); a batch of 1024 is four such waves per CU, and how close its time stays to this is how little they
+    # cost each other.  The cycle-level decomposition (stamps build, scripts/latency_floor.py) rides along while
+    # the kernels it was measured on are the ones running now. ----
+    if a.config == 1:
+        try:
+            from hnsw_rs_amd.distributed import make_device_search
+            ls_few = make_device_search(index, n, ef, 64, c.dev)
+            qf = [c.dQ[b][:64].contiguous() for b in range(nqb)]
+            for i in range(5):
+                ls_few(qf[i % nqb])
+            torch.cuda.synchronize()
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
+            for i in range(50):
+                ls_few(qf[i % nqb])
+            g1.record()
+            torch.cuda.synchronize()
+            ms_few = g0.elapsed_time(g1) / 50
+            lf = {"kernel_ms_64_queries": round(ms_few, 5), "kernel_ms_1024_queries": round(kern_ms, 5),
+                  "floor_over_kernel": round(ms_few / kern_ms, 4),
+                  "note": "a query's ~%d dependent expansions cannot run faster than this whatever the batch size: against "
+                          "THIS roof the 1024-query launch is at %.0f %%; the HBM roofline above is the roof of the "
+                          "machine-filling regime (launches of >= 8192 queries: DESIGN.md section 10)" % (
+                              round(float(st[:, 1].mean())), 100.0 * ms_few / kern_ms)}
+            ffile = os.path.join(ROOT, "profiles", "latency_floor_latest.json")
+            if os.path.exists(ffile):
+                fdoc = json.load(open(ffile))
+                if fdoc.get("kernel_sources_sha16") == kernel_sources_sha16() and fdoc.get("vec_kind") == kind_name and fdoc.get("efSearch") == ef:
+                    lf["dependent_steps"] = fdoc.get("launches")
+                    lf["dependent_steps_note"] = fdoc.get("note")
+            out["latency_floor"] = lf
+        except Exception as e:
+            log("latency floor skipped: %s" % e)
     # Not the metric: the same 1024-query launches with several batches in flight (one stream each).
     # A 1024-query launch puts one wave on every SIMD; independent batches share the SIMDs and hide each
     # other's memory waits, which is what a server with concurrent requests sees.

@@ -1094,15 +1094,20 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
                 std::chrono::duration<double>(t_stored - t_enter).count(), std::chrono::duration<double>(t_prep - t_stored).count(),
                 std::chrono::duration<double>(t_ordered - t_prep).count(),
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ordered).count());
-    if (n_before < SEED) {
-        const size_t take = std::min<size_t>(order.size(), SEED - n_before);
+    // The first points are inserted one after the other on the host (the graph depends on it).  Unless they are all
+    // there is to insert, that runs WHILE the vector rows travel to HBM (DeviceIndex::upload's side job): the rows are
+    // immutable once stored, the adjacency -- which the seed writes -- is packed after the seed has finished.
+    const size_t take = n_before < SEED ? std::min<size_t>(order.size(), SEED - n_before) : 0;
+    std::vector<uint64_t> restore;
+    auto seed_and_clamp = [&]() -> int {
         for (size_t i = 0; i < take; i++) {
-            rc = host.insert(order[i], *ins);
-            if (rc != HNSW_OK) return rc;
+            const int r = host.insert(order[i], *ins);
+            if (r != HNSW_OK) return r;
         }
-        pos = take;
-    }
-    if (pos == order.size() || host.nb_layers() > 16) {  // edge records carry 4-bit layers
+        clamp_rows_to_cap(host, &restore);
+        return HNSW_OK;
+    };
+    if (take == order.size() || host.nb_layers() > 16) {  // nothing for the device (edge records carry 4-bit layers)
         for (; pos < order.size(); pos++) {
             rc = host.insert(order[pos], *ins);
             if (rc != HNSW_OK) return rc;
@@ -1110,14 +1115,13 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         host.version++;
         return HNSW_OK;
     }
+    pos = take;
     const auto t_start = std::chrono::steady_clock::now();
-    std::vector<uint64_t> restore;
-    clamp_rows_to_cap(host, &restore);
-    const auto t_clamped = std::chrono::steady_clock::now();
+    const auto t_clamped = t_start;
     const int saved_inline = h->dev.inline_rows;
     h->dev.inline_rows = 0;
     h->dev.release();
-    rc = h->dev.upload(host, h->device);
+    rc = h->dev.upload(host, h->device, seed_and_clamp);
     h->dev.inline_rows = saved_inline;
     if (rc != HNSW_OK) return rc;
     h->device = h->dev.device;
@@ -1497,9 +1501,9 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
             return std::chrono::duration<double>(y - x).count();
         };
         fprintf(stderr,
-                "host phases: store_points %.2f s, levels + order + first %llu points on the CPU %.2f s, row clamp %.2f s, "
+                "host phases: store_points %.2f s, levels + order %.2f s, (row clamp %.2f s,) first %llu points on the CPU beside the "
                 "upload %.2f s, buffers %.2f s, batch loop %.2f s\n",
-                secs(t_enter, t_stored), (unsigned long long)SEED, secs(t_stored, t_start), secs(t_start, t_clamped),
+                secs(t_enter, t_stored), secs(t_stored, t_start), secs(t_start, t_clamped), (unsigned long long)SEED,
                 secs(t_clamped, t_uploaded), secs(t_uploaded, t_loop0), secs(t_loop0, t_sync0));
     }
     host.version++;

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -516,7 +517,7 @@ int DeviceIndex::read_adjacency(int which, uint64_t n_rows,
     return HNSW_OK;
 }
 
-int DeviceIndex::upload(const HostIndex &idx, int dev) {
+int DeviceIndex::upload(const HostIndex &idx, int dev, const std::function<int()> &meanwhile) {
     const uint64_t N = idx.len();
     if (N == 0) {
         set_error("index is empty");
@@ -532,14 +533,29 @@ int DeviceIndex::upload(const HostIndex &idx, int dev) {
     HIP_TRY(hipSetDevice(dev));
     device = dev;
 
+    // the caller's side job: started now, joined before anything but the vector rows is read from idx (and on every
+    // way out of this function)
+    struct Side {
+        std::thread t;
+        int rc = HNSW_OK;
+        std::string err;
+        void join() {
+            if (t.joinable()) t.join();
+        }
+        ~Side() { join(); }
+    } side;
+    if (meanwhile)
+        side.t = std::thread([&side, &meanwhile] {
+            side.rc = meanwhile();
+            if (side.rc != HNSW_OK) side.err = get_error();
+        });
+
     DevView v{};
     v.kind = idx.kind;
     v.n_points = (uint32_t)N;
     v.dim = idx.dim;
     v.nch4 = 4 * (idx.dim / 8);
     v.rem = idx.dim % 8;
-    v.nb_layers = idx.nb_layers();
-    v.ep = idx.params.ep;
     const bool q8 = idx.kind == HNSW_VEC_QUANT8;
     v.half_bytes = q8 ? quant_half_bytes(idx.dim) : 0;
     v.row_stride = q8 ? 2 * v.half_bytes : f32_row_stride(idx.dim);
@@ -592,6 +608,13 @@ int DeviceIndex::upload(const HostIndex &idx, int dev) {
             if (want_fat) memcpy(&rows_h[lo * v.row_stride], dst, (hi - lo) * v.row_stride);
         });
         if (rc != HNSW_OK) return rc;
+        side.join();
+        if (side.rc != HNSW_OK) {
+            set_error("%s", side.err.c_str());
+            return side.rc;
+        }
+        v.nb_layers = idx.nb_layers();
+        v.ep = idx.params.ep;
         if (want_fat) adj0_h.resize((size_t)N * v.S0);
         std::mutex over_mu;
         rc = upload_pieces(pp, bufs_[1], N, (size_t)v.S0 * 4, [&](uint64_t lo, uint64_t hi, unsigned char *dst) {

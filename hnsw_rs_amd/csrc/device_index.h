@@ -143,7 +143,10 @@ int launch_fat_rebuild(const DevView &v, uint8_t *fat, const uint32_t *d_nodes, 
 class DeviceIndex {
   public:
     ~DeviceIndex() { release(); }
-    int upload(const HostIndex &idx, int device);
+    // meanwhile (optional) runs on another thread while the vector rows -- the bulk of a snapshot, and immutable once
+    // stored -- are on the wire; the adjacency is packed after it has returned (the on-device build seeds its graph
+    // on the host there: 0.8 s beside a 0.7-s upload at 16M x 256d)
+    int upload(const HostIndex &idx, int device, const std::function<int()> &meanwhile = {});
     // inline-rows layout: -1 = auto (build it when it fits fat_budget_bytes), 0 = never, 1 = always
     int inline_rows = -1;
     uint64_t fat_budget_bytes = 64ull << 30;

@@ -72,5 +72,12 @@ for nq in (64, 1024):
     res[str(nq)] = r
     print(json.dumps(r))
 if outp:
-    json.dump({"efSearch": ef, "workload": "1M x 100d f32, M=16", "stamps_overhead_note": "the stamps themselves lengthen the kernel by ~10 %",
+    import hashlib
+    hh = hashlib.sha256()
+    for f in ("search_kernels.hip", "search_lean.hip", "coop_rows.inc", "search_common.h", "device_index.h"):
+        hh.update(open(os.path.join("hnsw_rs_amd", "csrc", f), "rb").read())
+    json.dump({"efSearch": ef, "vec_kind": "f32", "workload": "1M x 100d f32, M=16", "kernel_sources_sha16": hh.hexdigest()[:16],
+               "note": "stamps build (in-kernel cycle counters; they lengthen the kernel by ~10 %): floor = staging + upper layers + "
+                       "passes x (pick + adjacency round trip + the row gather measured alone [1850 cycles, a wave alone on its CU, "
+                       "scripts/micro/gather_latency.hip] + FullVec's chain), every piece of bookkeeping free",
                "launches": res}, open(outp, "w"), indent=1)

@@ -14,7 +14,8 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --output-format csv -d $OUT/p2 -- python $REPO/bench.py $ARGS > $OUT/p2.json 2> $OUT/p2.err || tail -3 $OUT/p2.err
 cd $REPO
 python - <<PY
-import csv, glob, collections
+import csv, glob, collections, json
+doc = {}
 for p in ("p1","p2"):
     f = glob.glob("$OUT/%s/**/*counter_collection.csv" % p, recursive=True)
     if not f: print("no csv for", p); continue
@@ -28,4 +29,7 @@ for p in ("p1","p2"):
     for k, v in acc.items():
         v = v[-50:]
         print("%-24s mean per launch %14.0f   per wave %10.1f" % (k, sum(v)/len(v), sum(v)/len(v)/1024))
+        doc[k] = sum(v)/len(v)
+    doc["kernel"] = timed[:80]
+json.dump(doc, open("$OUT/sq.json", "w"), indent=1)
 PY
