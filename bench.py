@@ -447,7 +447,7 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
     # with); a batch of 1024 is four such waves per CU, and how close its time stays to this is how little they
     # cost each other.  The cycle-level decomposition (stamps build, scripts/latency_floor.py) rides along while
     # the kernels it was measured on are the ones running now. ----
-    if a.config == 1:
+    if a.config == 1 and not a.no_extras:  # (profiling passes keep the kernel trace to full-size launches)
         try:
             from hnsw_rs_amd.distributed import make_device_search
             ls_few = make_device_search(index, n, ef, 64, c.dev)

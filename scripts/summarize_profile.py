@@ -43,7 +43,9 @@ for kind in ("f32", "quant8"):
                 print(", ".join(row))
     tr = find("trace_%s/**/*kernel_trace.csv" % kind)
     if tr:
-        rows = [r for r in csv.DictReader(open(tr)) if is_search(r.get("Kernel_Name", ""))]
+        grid = str(64 * line["config"]["batch_per_gpu"]) if line is not None else None  # full-size launches only
+        rows = [r for r in csv.DictReader(open(tr)) if is_search(r.get("Kernel_Name", ""))
+                and (grid is None or r.get("Grid_Size", r.get("Grid_Size_X")) == grid)]
         # the timed efSearch is the kernel instantiation with the most dispatches (warm-up + timed + the
         # counter pass); the recall ladder and the efSearch-64 side measurement use other list widths
         names = {}
@@ -65,8 +67,10 @@ for kind in ("f32", "quant8"):
         f = find("%s_%s/**/*counter_collection.csv" % (dname, kind))
         if not f:
             continue
+        grid = str(64 * line["config"]["batch_per_gpu"]) if line is not None else None
         prow = [r for r in csv.DictReader(open(f))
-                if is_search(r.get("Kernel_Name", "")) and r.get("Counter_Name") == cname]
+                if is_search(r.get("Kernel_Name", "")) and r.get("Counter_Name") == cname
+                and (grid is None or r.get("Grid_Size", r.get("Grid_Size_X")) == grid)]
         pn = {}
         for r in prow:
             pn[r["Kernel_Name"]] = pn.get(r["Kernel_Name"], 0) + 1
@@ -80,9 +84,9 @@ for kind in ("f32", "quant8"):
         fetch_kb, write_kb = res["FETCH_SIZE"], res.get("WRITE_SIZE", 0.0)
         hbm = int((2 * fetch_kb + write_kb) * 1024)
         alg = line["roofline"]["algorithmic_bytes_per_launch"]
-        print("HBM traffic per launch: read %.1f MB raw counter -> %.1f MB after the gfx950 x2 correction for "
-              "16-B/lane loads (MI355X_MICROARCH.md, HBM), write %.2f MB; algorithmic %.1f MB; ratio %.2f" % (
-                  fetch_kb / 1024, 2 * fetch_kb / 1024, write_kb / 1024, alg / 1e6, hbm / alg))
+        print("HBM traffic per launch (MB = 1e6 bytes throughout): read %.1f MB raw counter -> %.1f MB after the gfx950 x2 "
+              "correction for 16-B/lane loads (MI355X_MICROARCH.md, HBM), write %.2f MB; total %.1f MB; algorithmic %.1f MB; ratio %.2f" % (
+                  fetch_kb * 1024 / 1e6, 2 * fetch_kb * 1024 / 1e6, write_kb * 1024 / 1e6, hbm / 1e6, alg / 1e6, hbm / alg))
         a = line["config"]
         entries.append({"workload": a.get("index_tag") or "n%d_d%d_m%d_efc%d_%s_r0" % (a["n_points"], a["dim"], a["M"],
                                                                                         a["ef_construction"], kind),
