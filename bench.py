@@ -400,7 +400,7 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
     # HBM traffic comes from separate rocprofv3 PMC passes (scripts/profile.sh) and is only quoted while
     # the kernels it was measured on are the ones running now (hash of the kernel sources)
-    traffic, traffic_from = None, None
+    traffic, traffic_from, sq = None, None, None
     tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tfile):
         try:
@@ -409,7 +409,8 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
                 if tj.get("workload") == tag and tj.get("ef") == ef and tj.get("batch") == B:
                     if tdoc.get("kernel_sources_sha16") == kernel_sources_sha16():
                         traffic = tj.get("hbm_bytes_per_launch")
-                        traffic_from = {"commit": tdoc.get("commit"), "efSearch": ef, "profile": tdoc.get("profile")}
+                        traffic_from = {"commit": tdoc.get("commit"), "efSearch": ef, "profile": tj.get("profile", tdoc.get("profile"))}
+                        sq = tj.get("sq")
                     else:
                         traffic_from = {"stale": "kernels changed since commit %s; rerun scripts/profile.sh" % tdoc.get("commit")}
         except (OSError, ValueError, AttributeError):
@@ -429,6 +430,22 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
                       "sum_deg": round(float(st[:, 2].mean()), 2), "bytes": round(float(bq.mean()), 1),
                       "row_bytes": row_bytes},
     }
+    if sq and sq.get("SQ_WAVE_CYCLES"):
+        # The other roofs of the same kernel, from the SQ counters of a separate PMC pass (scripts/pmc_sq.sh): a wave
+        # alone on its SIMD (a 1024-query launch) is bound by its own instruction stream and its waits, not by bytes.
+        # SQ_WAVE_CYCLES and the SQ_WAIT_* / SQ_ACTIVE_* counters tick once per four clocks; a vector instruction holds
+        # its SIMD's issue for four clocks, so instructions / wave-cycles IS the fraction of the VALU issue roof.
+        wc = float(sq["SQ_WAVE_CYCLES"])
+        out["roofline"]["issue"] = {
+            "valu_issue_frac": round(sq.get("SQ_INSTS_VALU", 0.0) / wc, 4),
+            "salu_issue_frac": round(sq.get("SQ_INSTS_SALU", 0.0) / wc, 4),
+            "waiting_frac": round(sq.get("SQ_WAIT_ANY", 0.0) / wc, 4),
+            "instruction_fetch_wait_frac": round(sq.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4),
+            "per_query": {"valu": round(sq.get("SQ_INSTS_VALU", 0.0) / B, 1), "salu": round(sq.get("SQ_INSTS_SALU", 0.0) / B, 1),
+                          "lds": round(sq.get("SQ_INSTS_LDS", 0.0) / B, 1), "vmem_rd": round(sq.get("SQ_INSTS_VMEM_RD", 0.0) / B, 1),
+                          "wave_cycles_x4": round(wc / B, 1)},
+            "note": "valu_issue_frac = SQ_INSTS_VALU x 4 clocks / (SIMDs x the kernel's clocks) with one wave per SIMD; "
+                    "counters from the profile named in traffic_measured_at"}
     out["recall_at_%d" % n] = recall_by_ef[ef]
     out["ground_truth"] = getattr(c, "ground_truth", None)
     out["recall_by_ef"] = {str(k): v for k, v in sorted(recall_by_ef.items())}
@@ -593,7 +610,7 @@ def extras(c, index, kind_name, ef, local_search):
             gate = threading.Barrier(C + 1)
 
             def work(t):
-                for i in range(4):  # every caller's stream and staging exist before the clock starts
+                for i in range(10):  # every caller's stream and staging exist before the clock starts
                     index.search_batch(qh[(i + t) % nqb], n, ef)
                 gate.wait()
                 for i in range(2 * steps):

@@ -26,6 +26,40 @@ if os.path.exists(os.path.join(out2, "traffic_c2.json")):
                                     "how": "scripts/profile_c2.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of the same command, (2 x FETCH_SIZE + WRITE_SIZE) KB, merged into this line afterwards"}
     open(os.path.join(prof, tag + "_bench_line_config2_10Mx768.json"), "w").write(json.dumps(line) + "\n")
     print("configs[2]: %.0f q/s, %.3f ms, frac %.4f, traffic %.2f GB" % (line["value"], line["ms_per_step"], r["frac"], r["traffic"] / 1e9))
+# configs[3] / configs[4] (scripts/profile_cfg.sh): search-kernel traffic per launch, and the build's insert kernel
+for cfg, name in ((3, "config3_100Mx128d_one_gpu"), (4, "config4_16Mx256d_one_gpu")):
+    oc = os.path.join(ROOT, "gpurun_out", "%s_c%d" % (tag, cfg))
+    tf = os.path.join(oc, "traffic_c%d.json" % cfg)
+    if not os.path.exists(tf):
+        continue
+    ents = json.load(open(tf))
+    keys = {(e["workload"], e.get("kernel")) for e in ents}
+    t["entries"] = [e for e in t["entries"] if (e["workload"], e.get("kernel")) not in keys] + ents
+    shutil.copy(os.path.join(oc, "summary.txt"), os.path.join(prof, "%s_%s_summary.txt" % (tag, name)))
+    line = json.loads(open(os.path.join(oc, "bench.json")).read().strip().splitlines()[-1])
+    for e in ents:
+        how = {"commit": t["commit"], "profile": e.get("profile"), "how": "scripts/profile_cfg.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+               "separate passes of the same command, (2 x FETCH_SIZE + WRITE_SIZE) KB, merged into this line afterwards"}
+        if e.get("kernel") == "hx_insert_kernel" and line.get("build_roofline") and line["build_roofline"]["traffic"] is None:
+            line["build_roofline"]["traffic"] = e["hbm_bytes_all_launches"]
+            line["build_roofline"]["traffic_measured_at"] = how
+        elif e.get("kernel") is None and line["roofline"]["traffic"] is None:
+            line["roofline"]["traffic"] = e["hbm_bytes_per_launch"]
+            line["roofline"]["traffic_measured_at"] = how
+    open(os.path.join(prof, "%s_bench_line_%s.json" % (tag, name)), "w").write(json.dumps(line) + "\n")
+    print("configs[%d]: value %.0f %s, search frac %.4f, traffic %s" % (cfg, line["value"], line["unit"], line["roofline"]["frac"], line["roofline"]["traffic"]))
+# SQ counters of the timed kernels (scripts/pmc_sq.sh KIND EF -> gpurun_out/sq_KIND_EF/sq.json): ride on the entries
+for e in t["entries"]:
+    if e.get("kernel") is not None or "ef" not in e:
+        continue
+    kind = "quant8" if "_quant8_" in e["workload"] else "f32"
+    sqf = os.path.join(ROOT, "gpurun_out", "sq_%s_%d" % (kind, e["ef"]), "sq.json")
+    if os.path.exists(sqf) and e["workload"].startswith("n1000000_d100_"):
+        e["sq"] = json.load(open(sqf))
+lf = os.path.join(prof, "latency_floor_latest.json")
+if os.path.exists(lf):
+    fdoc = json.load(open(lf))
+    print("latency floor file: sources %s (%s)" % (fdoc.get("kernel_sources_sha16"), "current" if fdoc.get("kernel_sources_sha16") == bench.kernel_sources_sha16() else "STALE"))
 json.dump(t, open(os.path.join(prof, "traffic_latest.json"), "w"), indent=1)
 b = json.load(open(os.path.join(prof, tag + "_bench_line.json")))
 print("configs[1]: %.0f q/s, frac %.4f; traffic file for commit %s, sources %s" % (b["value"], b["roofline"]["frac"], t["commit"], t["kernel_sources_sha16"]))

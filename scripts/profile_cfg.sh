@@ -29,4 +29,6 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$RX" --output-
 echo "[profile_cfg] WRITE_SIZE pass done" >&2
 cd $REPO
 python scripts/summarize_cfg_profile.py $OUT $CFG > $OUT/summary.txt
+# the raw traces of a run with tens of thousands of build dispatches are hundreds of MB: gpurun merges back 64 MiB at most
+rm -rf $OUT/pmc_fetch $OUT/pmc_write
 cut -c1-600 $OUT/summary.txt
