@@ -1092,6 +1092,7 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
 template <class LT>
 __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
     constexpr int R = LT::NR;
+    constexpr bool SPILLV = R >= 6;  // ef > 320: the visited set may continue in HBM (Visited::look2)
     constexpr int DS = 100, P = 4, NQ = 4 * (DS / 8) + DS % 8;  // 52 query values per half (half 1 uses 48)
     constexpr uint32_t HALF = 64, ROW = 128, NCH4 = 4 * (DS / 8), REM = DS % 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1152,7 +1153,18 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
     };
     // exact insert of the even lanes' ids; both lanes of a pair learn the outcome
     auto pair_insert = [&](uint32_t id, bool ins) __attribute__((always_inline)) -> bool {
-        const bool f = vis.insert(id, ins && h == 0);
+        bool f;
+        if constexpr (SPILLV) {  // (both levels once the LDS level is closed)
+            const bool mine = ins && h == 0;
+            const uint32_t b0 = vis.home(id);
+            const uint32_t t0 = vis.look2(id, b0, mine, mine);
+            const uint32_t t = mine ? t0 : 4u;
+            const uint32_t old = vis.claim2(id, b0, t);
+            f = old == HX_EMPTY_SLOT;
+            f = vis.finish2(id, b0, t, (t != 4u) & !f, f);
+        } else {
+            f = vis.insert(id, ins && h == 0);
+        }
         return (pair_swap_i(f ? 1 : 0) | (f ? 1 : 0)) != 0;
     };
 
@@ -1273,7 +1285,19 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
     if (status == HNSW_OK) {
         vis.bshift = 32 - (a.slots_log2 - 2);
         vis.bmask = (hslots >> 2) - 1;
-        const uint32_t vis_limit = hslots - (hslots >> 2);  // 75 % load at most
+        uint32_t lds_limit = hslots - (hslots >> 2);  // 75 % load at most
+        if constexpr (SPILLV) {
+            if (a.spill_tab != nullptr && a.lds_limit != 0) lds_limit = min(lds_limit, max(128u, a.lds_limit));
+        }
+        uint32_t vis_limit = lds_limit;
+        if constexpr (SPILLV) {
+            if (a.spill_tab != nullptr) {  // a second level in HBM takes what the LDS table cannot (Visited)
+                vis.gtab = a.spill_tab + ((size_t)blockIdx.x << a.spill_log2);
+                vis.gmask = (1u << a.spill_log2) - 1;
+                vis.gshift = 32 - a.spill_log2;
+                vis_limit = lds_limit + (1u << a.spill_log2) / 2;
+            }
+        }
         vis.clear(hslots, lane);
         vis.insert(cur, lane == 0);
         n_vis = 1;
@@ -1290,6 +1314,10 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
         // f32 kernel's two-candidate pass with the wanted rows packed onto the pairs: + 6 to + 10 %.)
         while (true) {
             STAMP(f0);
+            if constexpr (SPILLV) {
+                // the LDS table has reached its limit (it may hold 32 more: one pass): closed from this pass on
+                if (HX_UNLIKELY(!vis.spill && vis.gtab != nullptr && n_vis + 64u > lds_limit)) vis.open_second_level(lane);
+            }
             typename LT::Masks U;
             lst.unexp_masks(U);
             const int cpos = lst.take_first(U);
@@ -1322,12 +1350,16 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
             const bool valid = (int32_t)nb >= 0;
             // ---- visited: the pair looks at the id's home bucket, the even lane claims a slot ----
             const uint32_t vb = vis.home(nb);
-            const uint32_t vt0 = vis.look(nb, vb);
+            uint32_t vt0;
+            if constexpr (SPILLV)
+                vt0 = vis.look2(nb, vb, valid && h == 0, valid && h == 0);  // (7: claimed in the HBM level at the look)
+            else
+                vt0 = vis.look(nb, vb);
             const uint32_t ct = (valid && h == 0) ? vt0 : 4u;
-            const uint32_t old = vis.claim(nb, vb, ct);
+            const uint32_t old = SPILLV ? vis.claim2(nb, vb, ct) : vis.claim(nb, vb, ct);
             bool fresh0 = old == HX_EMPTY_SLOT;
             const bool pend = (ct != 4u) & !fresh0;
-            if (__ballot(pend)) fresh0 = vis.finish(nb, vb, ct, pend, fresh0);
+            if (__ballot(pend)) fresh0 = SPILLV ? vis.finish2(nb, vb, ct, pend, fresh0) : vis.finish(nb, vb, ct, pend, fresh0);
             const bool fresh = (pair_swap_i(fresh0 ? 1 : 0) | (fresh0 ? 1 : 0)) != 0;
             const u64 vmask = __ballot(valid && h == 0), fmask = __ballot(fresh0);
             const uint32_t nf = (uint32_t)__popcll(fmask);
@@ -1367,6 +1399,11 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
                     if (n_vis + ocnt > vis_limit) {
                         status = HNSW_ERR_OVERFLOW;
                         break;
+                    }
+                    if constexpr (SPILLV) {
+                        // a long overflow list must not run the LDS table full between two passes: the same switch
+                        // as at the top of a pass, before every 32 ids
+                        if (HX_UNLIKELY(!vis.spill && vis.gtab != nullptr && n_vis + 64u > lds_limit)) vis.open_second_level(lane);
                     }
                     const bool ofresh = pair_insert(onb, ov);
                     const uint32_t onf = (uint32_t)__popcll(__ballot(ofresh && h == 0));
@@ -1422,8 +1459,31 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
 }
 
 template <class LT>
-int launch_lean_q8(const LeanArgs &a, uint32_t nblocks, hipStream_t stream) {
+int launch_lean_q8(const LeanArgs &a_in, uint32_t nblocks, hipStream_t stream) {
     constexpr int R = LT::NR;
+    LeanArgs a = a_in;
+    // six- to eight-register lists (320 < ef <= 512): 32 KiB of LDS table + a second level in HBM, as launch_lean_one
+    struct Scratch {
+        void *p = nullptr;
+        hipStream_t st = nullptr;
+        ~Scratch() {
+            if (p) (void)hipFreeAsync(p, st);
+        }
+    } sp;
+    static const bool two_level = !(getenv("HNSW_MI355X_VISITED_2L") && atoi(getenv("HNSW_MI355X_VISITED_2L")) == 0);
+    if (R >= 6 && two_level && a.slots_log2 > 13) {
+        const uint32_t glog2 = std::max(15u, a.slots_log2 + 1);
+        sp.st = stream;
+        if (hipMallocAsync(&sp.p, ((size_t)nblocks << glog2) * 4, stream) != hipSuccess) {
+            (void)hipGetLastError();
+            sp.p = nullptr;
+        } else {
+            a.spill_tab = static_cast<uint32_t *>(sp.p);
+            a.spill_log2 = glog2;
+            a.slots_log2 = 13;
+            if (const char *e = getenv("HNSW_MI355X_VISITED_2L_LIMIT")) a.lds_limit = (uint32_t)atoi(e);
+        }
+    }
     const size_t lds = (4ull << a.slots_log2) + (64ull * R + 64) * 8 + 2 * 56 * 4;
     auto kern = hx_lean_q8_kernel<LT>;
     if (lds > 160 * 1024) {
@@ -1516,8 +1576,11 @@ bool lean_applicable(const DevView &v, const SearchArgs &a, uint32_t ef_max) {
     // lists: one register (ef <= 64), head + tail (<= 128), four interleaved registers (<= 256, HNSW_MI355X_LEAN_WIDE=0
     // sends those to the generic kernel, for A/B runs)
     static const bool wide = !(getenv("HNSW_MI355X_LEAN_WIDE") && atoi(getenv("HNSW_MI355X_LEAN_WIDE")) == 0);
-    // (eight registers, ef <= 512: f32 100d only -- x 1.28 against the generic kernel; quant8 gains nothing there)
-    if (v.S0 > 32 || v.S1 > 64 || ef_max > (wide ? (v.dim == 100 && v.kind == HNSW_VEC_F32 ? 512u : 256u) : 128u) || (a.flags & 1u)) return false;
+    // (five to eight registers, 256 < ef <= 512: d = 100, both kinds -- round 3: f32 only, x 1.28 against the generic kernel,
+    // quant8 gained nothing with the one-level 64-KiB table; round 4: the two-level visited set keeps four waves per CU)
+    static const bool q8_wide = !(getenv("HNSW_MI355X_LEAN_Q8_WIDE") && atoi(getenv("HNSW_MI355X_LEAN_Q8_WIDE")) == 0);
+    const bool to512 = v.dim == 100 && (v.kind == HNSW_VEC_F32 || q8_wide);
+    if (v.S0 > 32 || v.S1 > 64 || ef_max > (wide ? (to512 ? 512u : 256u) : 128u) || (a.flags & 1u)) return false;
     return true;
 }
 
@@ -1548,6 +1611,10 @@ int launch_lean(const DevView &v, const SearchArgs &s, uint32_t nblocks, uint32_
     static const bool interleaved = getenv("HNSW_MI355X_LIST") && getenv("HNSW_MI355X_LIST")[0] == 'i';
     if (v.kind == HNSW_VEC_QUANT8) {
         if (a.ef <= 64) return launch_lean_q8<Lst<1>>(a, nblocks, stream);
+        if (a.ef > 448) return launch_lean_q8<Lst<8>>(a, nblocks, stream);  // (round 4: 256 < ef <= 512 with the two-level visited set)
+        if (a.ef > 384) return launch_lean_q8<Lst<7>>(a, nblocks, stream);
+        if (a.ef > 320) return launch_lean_q8<Lst<6>>(a, nblocks, stream);
+        if (a.ef > 256) return launch_lean_q8<Lst<5>>(a, nblocks, stream);
         if (a.ef > 128) return launch_lean_q8<Lst<4>>(a, nblocks, stream);
         if (interleaved) return launch_lean_q8<Lst<2>>(a, nblocks, stream);
         return launch_lean_q8<LstHT>(a, nblocks, stream);

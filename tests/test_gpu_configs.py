@@ -85,9 +85,10 @@ def test_upload_without_pinned_staging_memory():
     assert out.returncode == 0 and "plain staging ok" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("kind", [H.VEC_F32, H.VEC_QUANT8])
 @pytest.mark.parametrize("limit", ["", "300", "2000"])
-def test_two_level_visited_set_of_the_eight_register_kernel(limit):
-    """320 < ef <= 512 at d = 100 f32 (round 4): the LDS visited table stays at 32 KiB and the ids beyond its limit
+def test_two_level_visited_set_of_the_eight_register_kernel(limit, kind):
+    """320 < ef <= 512 at d = 100, f32 and quant8 rows (round 4): the LDS visited table stays at 32 KiB and the ids beyond its limit
     go to a second level in HBM (Visited::look2, search_lean.hip).  HNSW_MI355X_VISITED_2L_LIMIT closes the LDS
     level after 300 / 2000 ids, so that every query crosses into the second level early / half way; results and
     counters must be the one-level table's, i.e. the oracle's (IntSet, results.rs:101-103).  Also the retry with a
@@ -100,7 +101,7 @@ def test_two_level_visited_set_of_the_eight_register_kernel(limit):
         "n, d, m = 60000, 100, 16\n"
         "vs = H.synth_rows(0, 0x5EED0001, 0, n, d); qs = H.synth_rows(0, 0x5EED0002, 0, 192, d)\n"
         "lv = O.draw_levels(n, m, 7)\n"
-        "idx = H.HNSW.new(m, 32, d, H.VEC_F32); idx.insert_bulk_device(vs, 8, False, levels=lv)\n"
+        "idx = H.HNSW.new(m, 32, d, %d); idx.insert_bulk_device(vs, 8, False, levels=lv)\n"
         "orc = oracle_from_product(idx, vs, lv)\n"
         "for ef in (321, 384, 448, 512):\n"
         "    got = idx.search_batch(qs, 10, ef)\n"
@@ -119,7 +120,7 @@ def test_two_level_visited_set_of_the_eight_register_kernel(limit):
         "orc2 = oracle_from_product(idx, vs, lv)\n"
         "for ef in (400, 512):\n"
         "    assert_search_equal(idx.search_batch(qs, 10, ef), orc2.search_batch(qs, 10, ef, nthreads=8), 'hub ef=%%d' %% ef)\n"
-        "print('two-level ok')\n" % ROOT)
+        "print('two-level ok')\n" % (ROOT, kind))
     env = dict(os.environ)
     if limit:
         env["HNSW_MI355X_VISITED_2L_LIMIT"] = limit
