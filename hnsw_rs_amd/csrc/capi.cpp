@@ -692,10 +692,16 @@ int search_coalesced(hnsw_index *h, const float *q, uint32_t n, uint32_t ef, uin
     }
     co.ns_turn.fetch_add(ns_since(t_turn), std::memory_order_relaxed);
     const uint32_t nq = (uint32_t)(b->word.fetch_or(CoBatch::CLOSED, std::memory_order_acq_rel) & CoBatch::COUNT);
-    while (b->filed.load(std::memory_order_acquire) != nq) {  // joiners between their claim and their copy (~100 ns)
+    for (uint32_t spins = 0; b->filed.load(std::memory_order_acquire) != nq; spins++) {
+        // joiners between their claim and their copy (~100 ns) -- unless one of them was descheduled right there
+        // (a throttled CPU quota can hold a thread for a whole period): then stop burning the core it needs
+        if (spins < 2000) {
 #if defined(__x86_64__)
-        __builtin_ia32_pause();
+            __builtin_ia32_pause();
 #endif
+        } else {
+            std::this_thread::yield();
+        }
     }
     co.last_size.store(nq, std::memory_order_relaxed);
     co.n_batches.fetch_add(1, std::memory_order_relaxed);

@@ -26,7 +26,7 @@ qs = H.synth_rows(0, 0x5EED0002, 0, 10240, d, 16)
 print("index %d x %dd %s built in %.1fs" % (N, d, kind_name, time.time() - t0), flush=True)
 ref_ids, _, ref_c, _ = index.search_batch(qs, 10, ef)
 
-for window, depth in ((30, 2), (30, 3), (60, 2)):
+for window, depth in ((30, 3),):
     index.set_option("coalesce_us", window)
     index.set_option("coalesce_depth", depth)
     for T in (1, 16, 64, 256, 1024):

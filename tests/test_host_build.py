@@ -230,3 +230,39 @@ def test_cosine_option_normalises_rows_on_the_way_in():
         idx.insert_vec(np.zeros(24, dtype=np.float32))  # 0 / 0: no direction
     plain = H.HNSW.new(8, None, 24, H.VEC_F32).insert_bulk(vs, 2, False)
     assert np.array_equal(plain.get_point(3).get_vals(), vs[3])  # off by default
+
+
+def test_handle_options_and_counters_without_a_device(gpu_available):
+    """hnsw_set_option / hnsw_get_stat (round 4): the coalescer's knobs are range-checked, the counters exist and
+    start at zero, unknown names are refused; the thread harness checks its arguments and -- like every search
+    entry point -- fails loudly without a GPU instead of answering from the host"""
+    idx = H.HNSW.new(8, None, 12).insert_bulk(rand_vectors(200, 12, 3), 1, False)
+    for key in ("uploads", "point_patches", "patch_fallbacks", "coalesced_batches", "coalesced_queries", "coalesced_max_batch",
+                "coalesce_ns_window", "coalesce_ns_turn", "coalesce_ns_gpu", "coalesce_ns_handout", "build_points",
+                "build_batches", "build_rows_read", "build_adj_rows", "build_adj_ids", "build_records", "build_removals",
+                "build_insert_kernel_us", "build_insert_phase_us", "build_connect_us"):
+        assert idx.stat(key) == 0, key
+    for bad in ("nope", "build_nope", "coalesce_ns"):
+        with pytest.raises(H.HnswError):
+            idx.stat(bad)
+    idx.set_option("coalesce_us", 0)
+    idx.set_option("coalesce_us", -1)
+    idx.set_option("coalesce_depth", 4)
+    idx.set_option("coalesce_max", 256)
+    for key in ("coalesce_depth", "coalesce_max"):
+        with pytest.raises(H.HnswError):
+            idx.set_option(key, 0)
+    # insert_vec on an index whose snapshot was never uploaded: nothing to patch, nothing counted
+    node = idx.insert_vec(rand_vectors(1, 12, 4)[0])
+    assert node == 200 and idx.stat("point_patches") == 0 and idx.stat("patch_fallbacks") == 0
+    qs = rand_vectors(8, 12, 5)
+    with pytest.raises(H.HnswError):
+        idx.search_threads(qs, 3, 10, threads=0, seconds=0.01)
+    if not gpu_available:
+        with pytest.raises(H.HnswError) as e:
+            idx.search_threads(qs, 3, 10, threads=2, seconds=0.01)
+        assert e.value.code in (H._lib.ERR_NO_DEVICE, H._lib.ERR_HIP)
+        idx.set_option("coalesce_us", 30)
+        with pytest.raises(H.HnswError) as e:
+            idx.ann_by_vector(qs[0], 3, 10)  # the coalesced path
+        assert e.value.code in (H._lib.ERR_NO_DEVICE, H._lib.ERR_HIP)
