@@ -643,7 +643,11 @@ __global__ void __launch_bounds__(64) hx_lean_f32_kernel(const LeanArgs a) {
     const uint32_t q = a.qsel ? a.qsel[blockIdx.x] : blockIdx.x;
     const uint32_t hslots = 1u << a.slots_log2;
     u64 *perm = reinterpret_cast<u64 *>(smem + 4ull * hslots);
-    unsigned char *coop_img = reinterpret_cast<unsigned char *>(perm + 64 * R + 64);  // COOP: 4 KiB + 64 words
+    // COOP: the gather's stage image (4 KiB + 64 rank words) SHARES the merge's permutation buffer -- a distance pass
+    // ends before its merge starts, nothing in either region lives across a pass -- so that the eight-register list
+    // at d = 128 stays within a quarter of the CU's LDS (32 KiB table + 4.5 KiB: four waves per CU; with separate
+    // regions it was 41.5 KB, three waves, a batch of 1024 in two rounds: 7.4 us per expansion)
+    unsigned char *coop_img = reinterpret_cast<unsigned char *>(perm);
     uint32_t *coop_ids = reinterpret_cast<uint32_t *>(coop_img + HX_COOP_IMG_BYTES);
     Visited vis;
     vis.tab = reinterpret_cast<uint32_t *>(smem);
@@ -1471,7 +1475,7 @@ int launch_lean_q8(const LeanArgs &a_in, uint32_t nblocks, hipStream_t stream) {
         }
     } sp;
     static const bool two_level = !(getenv("HNSW_MI355X_VISITED_2L") && atoi(getenv("HNSW_MI355X_VISITED_2L")) == 0);
-    if (R >= 6 && two_level && a.slots_log2 > 13) {
+    if (R >= 6 && two_level && a.slots_log2 >= 13) {  // (also where 32 KiB would do for most queries: the few that fill it go on in HBM instead of being run again)
         const uint32_t glog2 = std::max(15u, a.slots_log2 + 1);
         sp.st = stream;
         if (hipMallocAsync(&sp.p, ((size_t)nblocks << glog2) * 4, stream) != hipSuccess) {
@@ -1521,7 +1525,7 @@ int launch_lean_one(const LeanArgs &a_in, uint32_t nblocks, hipStream_t stream) 
         }
     } sp;
     static const bool two_level = !(getenv("HNSW_MI355X_VISITED_2L") && atoi(getenv("HNSW_MI355X_VISITED_2L")) == 0);
-    if (R >= 6 && two_level && a.slots_log2 > 13) {
+    if (R >= 6 && two_level && a.slots_log2 >= 13) {  // (also where 32 KiB would do for most queries: the few that fill it go on in HBM instead of being run again)
         const uint32_t glog2 = std::max(15u, a.slots_log2 + 1);
         sp.st = stream;
         if (hipMallocAsync(&sp.p, ((size_t)nblocks << glog2) * 4, stream) != hipSuccess) {
@@ -1534,8 +1538,8 @@ int launch_lean_one(const LeanArgs &a_in, uint32_t nblocks, hipStream_t stream) 
             if (const char *e = getenv("HNSW_MI355X_VISITED_2L_LIMIT")) a.lds_limit = (uint32_t)atoi(e);  // (tests: close the LDS level early)
         }
     }
-    const size_t lds = (4ull << a.slots_log2) + (64ull * R + 64) * 8 +
-                       (coop_rows<HNSW_VEC_F32, DS>() ? HX_COOP_IMG_BYTES + 256 : 0);
+    const size_t lds = (4ull << a.slots_log2) +
+                       std::max<size_t>((64ull * R + 64) * 8, coop_rows<HNSW_VEC_F32, DS>() ? HX_COOP_IMG_BYTES + 256 : 0);
     auto kern = hx_lean_f32_kernel<DS, LT, CK>;
     if (lds > 160 * 1024) {
         set_error("search needs %zu bytes of LDS (> 160 KiB)", lds);
@@ -1579,7 +1583,7 @@ bool lean_applicable(const DevView &v, const SearchArgs &a, uint32_t ef_max) {
     // (five to eight registers, 256 < ef <= 512: d = 100, both kinds -- round 3: f32 only, x 1.28 against the generic kernel,
     // quant8 gained nothing with the one-level 64-KiB table; round 4: the two-level visited set keeps four waves per CU)
     static const bool q8_wide = !(getenv("HNSW_MI355X_LEAN_Q8_WIDE") && atoi(getenv("HNSW_MI355X_LEAN_Q8_WIDE")) == 0);
-    const bool to512 = v.dim == 100 && (v.kind == HNSW_VEC_F32 || q8_wide);
+    const bool to512 = (v.dim == 100 && (v.kind == HNSW_VEC_F32 || q8_wide)) || (v.dim == 128 && v.kind == HNSW_VEC_F32);
     if (v.S0 > 32 || v.S1 > 64 || ef_max > (wide ? (to512 ? 512u : 256u) : 128u) || (a.flags & 1u)) return false;
     return true;
 }
@@ -1629,6 +1633,8 @@ int launch_lean(const DevView &v, const SearchArgs &s, uint32_t nblocks, uint32_
         }();
         const bool few = nblocks <= 4 * n_cu;  // at most one wave per SIMD: the four-stage build (see the kernel)
         if (a.ef <= 64) return few ? launch_lean_one<128, Lst<1>, 4>(a, nblocks, stream) : launch_lean_one<128, Lst<1>, 2>(a, nblocks, stream);
+        if (a.ef > 384) return launch_lean_one<128, Lst<8>, 2>(a, nblocks, stream);  // (round 4: 256 < ef <= 512, two-level visited set)
+        if (a.ef > 256) return launch_lean_one<128, Lst<6>, 2>(a, nblocks, stream);
         if (a.ef > 128) return launch_lean_one<128, Lst<4>, 2>(a, nblocks, stream);
         return few ? launch_lean_one<128, LstHT, 4>(a, nblocks, stream) : launch_lean_one<128, LstHT, 2>(a, nblocks, stream);
     }

@@ -144,10 +144,11 @@ def test_lean_kernels_with_the_four_register_list(kind):
 def test_128d(kind):
     """configs[3] dimension"""
     idx, orc, qs = device_built(20000, 128, 16, kind)
-    # f32: ef <= 256 runs the lean kernel with the cooperative row gather (one list register up to 64, head +
-    # tail up to 128, four interleaved registers up to 256), 300 the generic kernel; n = 100 reaches into the
-    # tail register, n = 200 into the third and fourth of the interleaved ones
-    for ef in (1, 10, 64, 65, 100, 128, 129, 200, 256, 300):
+    # f32: the lean kernel with the cooperative row gather (one list register up to ef 64, head + tail up to 128,
+    # four interleaved registers up to 256, six / eight up to 384 / 512 with the two-level visited set: round 4),
+    # the generic kernel beyond; n = 100 reaches into the tail register, n = 200 into the third and fourth of the
+    # interleaved ones
+    for ef in (1, 10, 64, 65, 100, 128, 129, 200, 256, 257, 300, 384, 385, 512, 513):
         assert_search_equal(idx.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=8), "128d ef=%d" % ef)
     assert_search_equal(idx.search_batch(qs[:64], 100, 120), orc.search_batch(qs[:64], 100, 120, nthreads=8), "128d n=100")
     assert_search_equal(idx.search_batch(qs[:64], 200, 230), orc.search_batch(qs[:64], 200, 230, nthreads=8), "128d n=200")

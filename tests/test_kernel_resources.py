@@ -33,7 +33,7 @@ def test_lean_kernels_fit_two_waves_per_simd_without_agprs_or_scratch(tmp_path):
     timed = {k: v for k, v in kernels.items() if "hx_lean_f32_kernel" in k or "hx_lean_q8_kernel" in k}
     # f32 100d and quant8: one register, head + tail, interleaved two (A/B), interleaved four (ef 129..256); f32 128d
     # (cooperative gather): one register and head + tail at two stage depths each, interleaved four
-    assert len(timed) == 21, sorted(kernels)  # (+ five to eight interleaved registers for ef 257..512, f32 100d and quant8)
+    assert len(timed) == 23, sorted(kernels)  # (+ five to eight interleaved registers for ef 257..512: f32 100d, quant8; six / eight for f32 128d)
     for name, r in timed.items():
         assert r.get("ScratchSize", 0) == 0 and r.get("VGPRs Spill", 0) == 0, (name, r)
         if "ILi128E" in name or ("hx_lean_f32_kernel" in name and re.search(r"LstILi[5678]E", name)):
@@ -42,7 +42,8 @@ def test_lean_kernels_fit_two_waves_per_simd_without_agprs_or_scratch(tmp_path):
             # per SIMD; what must not come back is scratch or a ring that lives in AGPRs
             # (the six- to eight-register lists carry the second visited level's state too: 7 / 18 / 20 values in
             # AGPRs at one wave per SIMD, which is what a batch of 1024 runs at)
-            assert r.get("AGPRs", 0) <= (24 if re.search(r"LstILi[678]E", name) else 16), (name, r)
+            wide = re.search(r"LstILi[678]E", name)
+            assert r.get("AGPRs", 0) <= ((40 if "ILi128E" in name else 24) if wide else 16), (name, r)
             continue
         assert r.get("AGPRs", 0) == 0, (name, r)
         assert r.get("Occupancy", 0) >= 2, (name, r)
