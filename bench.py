@@ -602,26 +602,14 @@ def extras(c, index, kind_name, ef, local_search):
                                  "efSearch": ef, "entry": "hnsw_search_batch (host pointers; H2D of the queries, D2H of ids / "
                                  "distances / counts / statistics, status check and overflow retry included)",
                                  "note": "never reported as `value`"}
-        # several callers at once (the entry is re-entrant: each call leases its own stream and staging): the H2D of
-        # one call runs under the kernel of another
-        import threading
+        # the same entry from C threads (no interpreter in the loop: what a Rust caller sees), one and several
+        # callers at once -- the entry is re-entrant, each call leases its own stream and staging, and the copies of
+        # one call run under the kernel of another
+        qall = np.ascontiguousarray(c.queries.reshape(nqb, -1, a.dim)[:, :B].reshape(-1, a.dim))
         conc = {}
-        for C in (2, 4):
-            gate = threading.Barrier(C + 1)
-
-            def work(t):
-                for i in range(10):  # every caller's stream and staging exist before the clock starts
-                    index.search_batch(qh[(i + t) % nqb], n, ef)
-                gate.wait()
-                for i in range(2 * steps):
-                    index.search_batch(qh[(i + t) % nqb], n, ef)
-            th = [threading.Thread(target=work, args=(t,)) for t in range(C)]
-            [t.start() for t in th]
-            gate.wait()
-            t0 = time.perf_counter()
-            [t.join() for t in th]
-            conc[str(C)] = round(C * 2 * steps * B / (time.perf_counter() - t0), 1)
-        out["pcie_inclusive"]["queries_per_s_concurrent_callers"] = conc
+        for C in (1, 2, 4):
+            conc[str(C)] = round(index.batch_threads(qall, B, n, ef, C, 2 * steps), 1)
+        out["pcie_inclusive"]["queries_per_s_c_callers"] = conc
     except Exception as e:
         log("pcie-inclusive measurement skipped: %s" % e)
     # ---- the reference's own call pattern: ONE query per call, T host threads each blocked in its call

@@ -108,6 +108,8 @@ SYMBOLS = {
     "hnsw_snapshot_describe": (C.c_int, [vp, C.POINTER(SnapshotDesc)]),
     "hnsw_snapshot_adopt": (C.c_int, [vp, C.POINTER(SnapshotDesc)]),
     "hnsw_snapshot_commit": (C.c_int, [vp]),
+    "hnsw_bench_batch_threads": (C.c_int, [vp, f32p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                           C.POINTER(C.c_double)]),
     "hnsw_synth_rows": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, f32p, C.c_uint32]),
     "hnsw_draw_levels": (C.c_int, [C.c_uint32, C.c_uint64, u8p]),
 }

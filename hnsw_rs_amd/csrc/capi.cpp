@@ -2490,6 +2490,57 @@ int hnsw_bench_search_threads(hnsw_index *h, const float *Q, uint64_t nq, uint32
     }
     return HNSW_OK;
 }
+// `callers` host threads, each calling hnsw_search_batch (host pointers in and out) `calls` times on its own slice
+// of Q (caller t takes queries [t * nq, (t + 1) * nq) modulo total) into its own result buffers: what concurrent
+// batch callers of the C ABI see, without an interpreter in the loop.  *wall_s = the time from the first call to the
+// last return (every caller's stream and staging exist before the clock starts: two untimed calls each).
+int hnsw_bench_batch_threads(hnsw_index *h, const float *Q, uint64_t total, uint64_t nq, uint32_t n, uint32_t ef,
+                             uint32_t callers, uint32_t calls, double *wall_s) {
+    if (!h || !Q || !wall_s || nq == 0 || total < nq || n == 0 || callers == 0 || callers > 64 || calls == 0) return HNSW_ERR_ARG;
+    int rc = check_search_args(h, ef);
+    if (rc != HNSW_OK) return rc;
+    if ((rc = ensure_uploaded(h))) return rc;
+    const uint32_t d = h->dev.view.dim;
+    std::atomic<int> first_rc{HNSW_OK};
+    std::string first_msg;
+    std::mutex msg_mu;
+    std::atomic<uint32_t> ready{0};
+    std::atomic<bool> go{false};
+    const uint64_t slices = total / nq;
+    auto work = [&](uint32_t t) {
+        std::vector<uint32_t> ids(nq * n), counts(nq);
+        std::vector<float> dists(nq * n);
+        std::vector<hnsw_query_stats> st(nq);
+        auto one = [&](uint32_t i) {
+            const float *q = Q + ((t + (uint64_t)i * callers) % slices) * nq * d;
+            return hnsw_search_batch(h, q, nq, n, ef, ids.data(), dists.data(), counts.data(), st.data());
+        };
+        int r = one(0);
+        if (r == HNSW_OK) r = one(1);
+        ready.fetch_add(1);
+        while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+        for (uint32_t i = 0; i < calls && r == HNSW_OK && first_rc.load(std::memory_order_relaxed) == HNSW_OK; i++) r = one(i + 2);
+        if (r != HNSW_OK) {
+            std::lock_guard<std::mutex> g(msg_mu);
+            if (first_rc.load() == HNSW_OK) {
+                first_msg = hx::get_error();
+                first_rc.store(r);
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < callers; t++) th.emplace_back(work, t);
+    while (ready.load() < callers) std::this_thread::yield();
+    const auto t0 = std::chrono::steady_clock::now();
+    go.store(true, std::memory_order_release);
+    for (auto &t : th) t.join();
+    *wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (first_rc.load() != HNSW_OK) {
+        set_error("%s", first_msg.c_str());
+        return first_rc.load();
+    }
+    return HNSW_OK;
+}
 int hnsw_draw_levels(uint32_t m, uint64_t n, uint8_t *out) {
     if (!out || m < 2) return HNSW_ERR_ARG;
     hx::stdrng_levels(0, hx::default_ml(m), n, out);

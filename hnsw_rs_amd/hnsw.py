@@ -381,6 +381,17 @@ class HNSW:
         check(self._L.hnsw_get_stat(self._h, key.encode(), C.byref(b)))
         return b.value
 
+    def batch_threads(self, Q, nq, n, ef, callers, calls):
+        """hnsw_bench_batch_threads: `callers` host threads x `calls` hnsw_search_batch calls of nq queries each (host
+        pointers in and out); -> queries per second over all callers"""
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        if Q.ndim != 2 or Q.shape[1] != self.dim:
+            raise HnswError(_lib.ERR_BAD_DIM, "queries must be total x %d" % self.dim)
+        wall = C.c_double()
+        check(self._L.hnsw_bench_batch_threads(self._h, _p(Q, _f32p), Q.shape[0], int(nq), n, ef, int(callers), int(calls),
+                                               C.byref(wall)))
+        return callers * calls * nq / wall.value
+
     def search_threads(self, Q, n, ef, threads, seconds):
         """The reference's call pattern as a load (hnsw_bench_search_threads): `threads` host threads, each blocked in
         its own one-query hnsw_search call.  -> (ids [nq, n], counts [nq], calls, wall seconds,

@@ -325,6 +325,12 @@ int hnsw_bench_search_threads(hnsw_index *h, const float *Q, uint64_t nq, uint32
                               double seconds, uint32_t *ids, uint32_t *counts, uint64_t *calls, double *wall_s,
                               double *lat_us);
 
+/* `callers` host threads, each calling hnsw_search_batch(nq queries, host pointers) `calls` times on its own slice
+ * of Q (total x dim) into its own result buffers; *wall_s = first call to last return (two untimed calls per caller
+ * first).  What concurrent batch callers of the C ABI see. */
+int hnsw_bench_batch_threads(hnsw_index *h, const float *Q, uint64_t total, uint64_t nq, uint32_t n, uint32_t ef,
+                             uint32_t callers, uint32_t calls, double *wall_s);
+
 #ifdef __cplusplus
 }
 #endif
