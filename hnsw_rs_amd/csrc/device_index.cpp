@@ -403,9 +403,17 @@ static void parallel_span(uint64_t lo, uint64_t hi, F f) {
 // fill(row_lo, row_hi, dst): writes rows [row_lo, row_hi) of `unit` bytes each.
 namespace {
 constexpr size_t PIECE_BYTES = 64ull << 20;
+inline size_t piece_limit() {  // (HNSW_MI355X_UPLOAD_PIECE_MB: A/B runs of the staging piece size)
+    static const size_t v = [] {
+        const char *e = getenv("HNSW_MI355X_UPLOAD_PIECE_MB");
+        const long mb = e ? atol(e) : 0;
+        return mb > 0 ? (size_t)mb << 20 : PIECE_BYTES;
+    }();
+    return v;
+}
 struct PinnedPair {
     size_t piece_bytes;  // of each buffer: 64 MiB, less for a small index (pinning memory costs time too)
-    explicit PinnedPair(size_t largest_array) : piece_bytes(std::max<size_t>(4096, std::min(PIECE_BYTES, largest_array))) {}
+    explicit PinnedPair(size_t largest_array) : piece_bytes(std::max<size_t>(4096, std::min(piece_limit(), largest_array))) {}
     void *buf[2] = {nullptr, nullptr};
     bool pinned = true;  // false: the host refused to pin memory (a small memlock limit); plain buffers, blocking copies
     hipEvent_t ev[2] = {nullptr, nullptr};

@@ -76,6 +76,10 @@ struct SearchArgs {
     hnsw_query_stats *out_stats; // nq
     unsigned long long *dbg;     // diagnostic builds only (HX_STAMPS): nq x 6 cycle sums, else null
     uint32_t flags;              // bit 0: one row per pass (disables the two-row loops; HNSW_MI355X_ONE_ROW=1)
+    // second level of the visited set (lists of eight / sixteen registers, ef > 320; set by the launcher): 1 << spill_log2
+    // words of HBM per launched query, or null; lds_limit: ids the LDS level takes before it is closed (0 = 75 % of its slots)
+    uint32_t *spill_tab;
+    uint32_t spill_log2, lds_limit;
 };
 
 // one batch of the on-device build: insertion searches for point_ids[0..n) (search_kernels.hip)

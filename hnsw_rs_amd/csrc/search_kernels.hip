@@ -777,7 +777,23 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
     // 32-KiB visited table the wave stays within a quarter of the CU's LDS for every list width up to 512
     constexpr uint32_t PERM_BYTES = scratch_region_bytes<KIND, DS, R>();
     float *yq = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(perm) + PERM_BYTES);
-    const uint32_t vis_limit = hslots - (hslots >> 2);  // 75 % load at most
+    // the visited set: an LDS table at 75 % load at most, and -- lists of eight / sixteen registers, round 4 -- a second
+    // level in HBM for the ids beyond it, so that the table stays at 32 KiB and four waves per CU stay resident where a
+    // 64- / 128-KiB table left two / one (the scheme of search_lean.hip's Visited::look2: the LDS level is CLOSED once it
+    // holds its limit, later ids are claimed by one compare-and-swap in the HBM table, an id is in the set iff it is in
+    // either level and is only inserted after both were found not to hold it)
+    constexpr bool SPILLV = R >= 8;
+    uint32_t lds_limit = hslots - (hslots >> 2);
+    uint32_t *gtab = nullptr;
+    uint32_t gmask = 0, gshift = 0;
+    bool spill = false;  // wave-uniform: the LDS level is closed (reset at every layer)
+    if (SPILLV && a.spill_tab != nullptr) {
+        gtab = a.spill_tab + ((size_t)blockIdx.x << a.spill_log2);
+        gmask = (1u << a.spill_log2) - 1;
+        gshift = 32 - a.spill_log2;
+        if (a.lds_limit != 0) lds_limit = min(lds_limit, max(128u, a.lds_limit));
+    }
+    const uint32_t vis_limit = lds_limit + (gtab != nullptr ? (gmask + 1) / 2 : 0u);
     // FAT: two 64 x 16 x P byte buffers for the prefetched block (after yq, 16-byte aligned)
     const uint32_t yq_bytes =
         ((KIND == HNSW_VEC_QUANT8 ? 2u * (v.half_bytes - 8) * 4u : v.dim * 4u) + 15u) & ~15u;
@@ -900,11 +916,56 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
     // ---- one pass over up to CHUNK neighbour ids (one per lane group) ----
     // entries the visited table holds (exact: the overflow check adds the row's worst case before a pass)
     uint32_t n_vis = 0;
+    // IntSet::insert / contains over both levels (true = id was absent / is present)
+    auto vins = [&](uint32_t id) __attribute__((always_inline)) -> bool {
+        if constexpr (SPILLV) {
+            if (spill) {
+                if (visited_contains(htab, hmask, slots_log2, id)) return false;
+                uint32_t s2 = ((id * 0x9E3779B1u) >> gshift) & gmask;
+                while (true) {  // the compare-and-swap is the probe: it returns what the slot holds
+                    const uint32_t old = atomicCAS(gtab + s2, HX_EMPTY_SLOT, id);
+                    if (old == HX_EMPTY_SLOT) return true;
+                    if (old == id) return false;
+                    s2 = (s2 + 1) & gmask;
+                }
+            }
+        }
+        return visited_insert(htab, hmask, slots_log2, id);
+    };
+    auto vhas = [&](uint32_t id) __attribute__((always_inline)) -> bool {
+        if (visited_contains(htab, hmask, slots_log2, id)) return true;
+        if constexpr (SPILLV) {
+            if (spill) {
+                uint32_t s2 = ((id * 0x9E3779B1u) >> gshift) & gmask;
+                while (true) {
+                    const uint32_t cur = __hip_atomic_load(gtab + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cur == id) return true;
+                    if (cur == HX_EMPTY_SLOT) return false;
+                    s2 = (s2 + 1) & gmask;
+                }
+            }
+        }
+        return false;
+    };
+    // room for cnt more ids?  Closes the LDS level (and empties the HBM one) when they would take it past its limit:
+    // checked BEFORE every chunk of ids is inserted, so the LDS table never holds more than its limit
+    auto room = [&](uint32_t cnt) __attribute__((always_inline)) -> bool {
+        if constexpr (SPILLV) {
+            if (gtab != nullptr && !spill && n_vis + cnt > lds_limit) {
+                for (uint32_t s2 = lane; s2 < ((gmask + 1) >> 2); s2 += 64)
+                    reinterpret_cast<uint4 *>(gtab)[s2] = make_uint4(HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                spill = true;
+            }
+        }
+        return n_vis + cnt <= vis_limit;
+    };
     auto process = [&](uint32_t id, bool valid, bool visit, uint32_t ef_l, bool hidden_loads = false) {
         bool fresh = valid;
         if (visit) {
             bool f = false;
-            if (valid && h == 0) f = visited_insert(htab, hmask, slots_log2, id);
+            if (valid && h == 0) f = vins(id);
             if (LPC == 2) f = (pair_swap_i(f ? 1 : 0) | (f ? 1 : 0)) != 0;
             fresh = f;
         }
@@ -944,13 +1005,14 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                 make_uint4(HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT, HX_EMPTY_SLOT);
         wave_fence();
         n_vis = 0;
+        spill = false;  // an empty LDS table: open again
         // candidates ∪= selected, visited ∪= ids(selected)  (searcher.rs:32-33)
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t idx = 64u * r + lane;
             if (idx < wl.n_cur) {
                 wl.L[r] &= KEY_MASK;
-                visited_insert(htab, hmask, slots_log2, (uint32_t)wl.L[r]);
+                vins((uint32_t)wl.L[r]);
             }
         }
         n_vis = wl.n_cur;
@@ -1051,12 +1113,12 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                 const uint32_t cnt = (uint32_t)__popcll(__ballot(valid && h == 0));
                 if (cnt != 0) {
                     sum_deg += cnt;
-                    if (n_vis + cnt > vis_limit) {
+                    if (!room(cnt)) {
                         status = HNSW_ERR_OVERFLOW;
                         break;
                     }
                     bool f = false;
-                    if (valid && h == 0) f = visited_insert(htab, hmask, slots_log2, nb);
+                    if (valid && h == 0) f = vins(nb);
                     const bool fresh = (pair_swap_i(f ? 1 : 0) | (f ? 1 : 0)) != 0;
                     const u64 fm = __ballot(fresh && h == 0);
                     n_vis += (uint32_t)__popcll(fm);  // what the table really holds
@@ -1125,7 +1187,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                         const uint32_t onb = ov ? asm_ld32(v.ovf_nbrs + i) : HX_EMPTY_SLOT;
                         const uint32_t ocnt = (uint32_t)__popcll(__ballot(ov && h == 0));
                         sum_deg += ocnt;
-                        if (n_vis + ocnt > vis_limit) {
+                        if (!room(ocnt)) {
                             status = HNSW_ERR_OVERFLOW;
                             break;
                         }
@@ -1192,16 +1254,16 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                 const uint32_t cnt_c = (uint32_t)__popcll(vmask & 0xFFFFFFFFull);
                 const uint32_t cnt_p = (uint32_t)__popcll(vmask >> 32);
                 sum_deg += cnt_c;
-                if (n_vis + cnt_c > vis_limit) {
+                if (!room(cnt_c)) {
                     status = HNSW_ERR_OVERFLOW;
                     break;
                 }
                 bool want = false;
-                if (valid && !upper) want = visited_insert(htab, hmask, slots_log2, nb);
+                if (valid && !upper) want = vins(nb);
                 n_vis += (uint32_t)__popcll(__ballot(want && !upper));  // what the table really holds
                 // (the look-up runs after the inserts of this pass: what c just claimed is skipped)
                 wave_fence();
-                if (valid && upper && spec_ok) want = !visited_contains(htab, hmask, slots_log2, nb);
+                if (valid && upper && spec_ok) want = !vhas(nb);
                 n_dist += (uint32_t)__popcll(__ballot(want && !upper));
                 STAMP(f2);
                 STAMP_ADD(1, f1, f2);
@@ -1228,7 +1290,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                         const uint32_t onb = ov ? v.ovf_nbrs[i] : HX_EMPTY_SLOT;
                         const uint32_t ocnt = (uint32_t)__popcll(__ballot(ov && h == 0));
                         sum_deg += ocnt;
-                        if (n_vis + ocnt > vis_limit) {
+                        if (!room(ocnt)) {
                             status = HNSW_ERR_OVERFLOW;
                             break;
                         }
@@ -1255,14 +1317,14 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                     if ((npos >> 6) == r && lane == (npos & 63)) wl.L[r] |= KEY_EXPANDED;
                 n_exp++;
                 sum_deg += cnt_p;
-                if (n_vis + cnt_p > vis_limit) {
+                if (!room(cnt_p)) {
                     status = HNSW_ERR_OVERFLOW;
                     break;
                 }
                 // every valid neighbour of p goes through the filter now: one that c's commit inserted
                 // meanwhile is dropped, one that was skipped above was in the set already
                 bool fresh = false;
-                if (valid && upper) fresh = visited_insert(htab, hmask, slots_log2, nb);
+                if (valid && upper) fresh = vins(nb);
                 n_vis += (uint32_t)__popcll(__ballot(fresh));
                 n_dist += (uint32_t)__popcll(__ballot(fresh));
                 if (__ballot(fresh && nan)) {
@@ -1313,7 +1375,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                 const uint32_t cnt = (uint32_t)__popcll(__ballot(valid && h == 0));
                 if (cnt == 0) continue;
                 sum_deg += cnt;
-                if (n_vis + cnt > vis_limit) {
+                if (!room(cnt)) {
                     status = HNSW_ERR_OVERFLOW;
                     break;
                 }
@@ -1328,7 +1390,7 @@ hx_search_kernel(const DevView v, const SearchArgs a, const uint32_t slots_log2)
                     const uint32_t nb = valid ? v.ovf_nbrs[i] : HX_EMPTY_SLOT;
                     const uint32_t cnt = (uint32_t)__popcll(__ballot(valid && h == 0));
                     sum_deg += cnt;
-                    if (n_vis + cnt > vis_limit) {
+                    if (!room(cnt)) {
                         status = HNSW_ERR_OVERFLOW;
                         break;
                     }
@@ -2733,10 +2795,34 @@ uint32_t default_slots_log2(uint32_t ef) { return default_slots_log2(ef, 32); }
 uint32_t max_slots_log2(uint32_t ef) { return ef <= 64 * HX_MAX_R_WIDE ? 15 : 31; }  // (the spill kernel caps its table at 4 N slots)
 
 template <int KIND, int P, int DS, int R, bool FAT>
-static int launch_one(const DevView &v, const SearchArgs &a, uint32_t nblocks, uint32_t slots_log2,
+static int launch_one(const DevView &v, const SearchArgs &a_in, uint32_t nblocks, uint32_t slots_log2,
                       hipStream_t stream) {
     const size_t yq_bytes =
         (KIND == HNSW_VEC_QUANT8) ? 2ull * (v.half_bytes - 8) * 4 : (size_t)v.dim * 4;
+    SearchArgs a = a_in;
+    // lists of eight / sixteen registers (ef > 320 asks for a 64- / 128-KiB table): 32 KiB of LDS + a second level in
+    // HBM (stream-ordered scratch), see the kernel
+    struct Scratch {
+        void *p = nullptr;
+        hipStream_t st = nullptr;
+        ~Scratch() {
+            if (p) (void)hipFreeAsync(p, st);
+        }
+    } sp;
+    static const bool two_level = !(getenv("HNSW_MI355X_VISITED_2L") && atoi(getenv("HNSW_MI355X_VISITED_2L")) == 0);
+    if (R >= 8 && two_level && slots_log2 >= 14 && a.spill_tab == nullptr) {
+        const uint32_t glog2 = std::max(15u, slots_log2 + 1);
+        sp.st = stream;
+        if (hipMallocAsync(&sp.p, ((size_t)nblocks << glog2) * 4, stream) != hipSuccess) {
+            (void)hipGetLastError();
+            sp.p = nullptr;  // no scratch: the one-level table serves
+        } else {
+            a.spill_tab = static_cast<uint32_t *>(sp.p);
+            a.spill_log2 = glog2;
+            slots_log2 = 13;
+            if (const char *e = getenv("HNSW_MI355X_VISITED_2L_LIMIT")) a.lds_limit = (uint32_t)atoi(e);
+        }
+    }
     size_t lds = (4ull << slots_log2) + scratch_region_bytes<KIND, DS, R>() + ((yq_bytes + 15) & ~15ull);
     if (FAT) lds += 2ull * 1024 * (P > 0 ? P : 1);
     auto kern = hx_search_kernel<KIND, P, DS, R, FAT>;

@@ -128,6 +128,35 @@ def test_two_level_visited_set_of_the_eight_register_kernel(limit, kind):
     assert out.returncode == 0 and "two-level ok" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.parametrize("limit", ["", "400"])
+def test_two_level_visited_set_of_the_generic_kernel(limit):
+    """hx_search_kernel with eight / sixteen list registers (320 < ef <= 1024, every dimension and kind the lean kernels
+    do not serve): 32 KiB of LDS table + the second level in HBM (round 4); with HNSW_MI355X_VISITED_2L_LIMIT the LDS level
+    closes after 400 ids, so every query crosses over early.  Results and counters are the oracle's."""
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import hnsw_rs_amd as H\n"
+        "from oracle import oracle_py as O\n"
+        "from tests.util import oracle_from_product, assert_search_equal\n"
+        "for kind, d, n in ((H.VEC_QUANT8, 36, 40000), (H.VEC_F32, 256, 30000), (H.VEC_F32, 52, 30000), (H.VEC_QUANT8, 128, 30000)):\n"
+        "    m = 16\n"
+        "    vs = H.synth_rows(0, 0x5EED0001, 0, n, d); qs = H.synth_rows(0, 0x5EED0002, 0, 96, d)\n"
+        "    lv = O.draw_levels(n, m, 9)\n"
+        "    idx = H.HNSW.new(m, 32, d, kind); idx.insert_bulk_device(vs, 8, False, levels=lv)\n"
+        "    idx.set_option('inline_rows', 0)\n"
+        "    orc = oracle_from_product(idx, vs, lv)\n"
+        "    for ef in (321, 400, 512, 700, 1024):\n"
+        "        assert_search_equal(idx.search_batch(qs, 10, ef), orc.search_batch(qs, 10, ef, nthreads=8), 'generic two-level kind %%d d %%d ef %%d' %% (kind, d, ef))\n"
+        "    g, w = idx.search_layer(0, qs[0], np.arange(5, dtype=np.uint32), 600), orc.search_layer(0, qs[0], np.arange(5, dtype=np.uint32), 600)\n"
+        "    assert np.array_equal(g[0], w[0]) and np.array_equal(g[1].view(np.uint32), w[1].view(np.uint32)) and tuple(int(x) for x in g[2]) == tuple(int(x) for x in w[2]), 'search_layer seam'\n"
+        "print('generic two-level ok')\n" % ROOT)
+    env = dict(os.environ)
+    if limit:
+        env["HNSW_MI355X_VISITED_2L_LIMIT"] = limit
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "generic two-level ok" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.parametrize("kind", [H.VEC_QUANT8, H.VEC_F32])
 def test_lean_kernels_with_the_four_register_list(kind):
     """129 <= ef <= 512 at d = 100: the lean kernels with four and eight interleaved list registers (round 3; the
