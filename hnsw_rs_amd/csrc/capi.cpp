@@ -1186,6 +1186,22 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         (rc = dRef.alloc((size_t)REF_CAP * 8)))
         return rc;
     HIP_TRY(hipMemcpy(dLevels.p, host.levels.data(), host.len(), hipMemcpyHostToDevice));
+    // the edges' distances beside the adjacency for the length of this build (ConnectArgs: a prune then evaluates
+    // nothing); 0xFFFFFFFF = not known yet (the rows that predate this build: evaluated at their first prune).  128 B
+    // per point at m = 16; without the memory for it the build runs as before
+    DevBuf dAdjD0, dAdjDUp;
+    uint32_t *adjd0 = nullptr, *adjd_up = nullptr;
+    {
+        static const bool keep_dists = !(getenv("HNSW_MI355X_BUILD_EDGE_DISTS") && atoi(getenv("HNSW_MI355X_BUILD_EDGE_DISTS")) == 0);
+        const size_t b0 = (size_t)host.len() * v.S0 * 4, b1 = std::max<size_t>(1, host.adj_up.size()) * v.S1 * 4;
+        if (keep_dists && hipMalloc(&dAdjD0.p, b0) == hipSuccess && hipMalloc(&dAdjDUp.p, b1) == hipSuccess &&
+            hipMemset(dAdjD0.p, 0xFF, b0) == hipSuccess && hipMemset(dAdjDUp.p, 0xFF, b1) == hipSuccess) {
+            adjd0 = dAdjD0.as<uint32_t>();
+            adjd_up = dAdjDUp.as<uint32_t>();
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     // counters: [0] requests, [1] removals, [2] refusals (accumulate over the build), [3] status
     uint32_t *cnt = dCnt.as<uint32_t>();
     HIP_TRY(hipMemset(dCnt.p, 0, 64));
@@ -1232,6 +1248,8 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         a.out_status = dStatus.as<int32_t>();
         a.adj0_mut = h->dev.adj0_mut();
         a.adj_up_mut = h->dev.adj_up_mut();
+        a.adjd0_mut = adjd0;
+        a.adjd_up_mut = adjd_up;
         a.counters = dRead.as<unsigned long long>();
         uint32_t nreq = 0;
         auto timed_insert = [&](uint32_t nblocks, int adjust) -> int {
@@ -1380,6 +1398,8 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         ca.m = m;
         ca.adj0_mut = h->dev.adj0_mut();
         ca.adj_up_mut = h->dev.adj_up_mut();
+        ca.adjd0_mut = adjd0;
+        ca.adjd_up_mut = adjd_up;
         ca.out_keys = dKeyA.as<uint64_t>();  // the unsorted requests are dead by now
         ca.out_count = cnt + 1;
         ca.out_cap = REQ_CAP;

@@ -94,6 +94,9 @@ struct InsertArgs {
     // full on-device connect (optional, all null otherwise): a point whose searches all succeeded
     // writes its own rows and appends one reverse-edge request per selected neighbour
     uint32_t *adj0_mut, *adj_up_mut;
+    // optional (round 4): the distance of every edge beside its id, same shape as the adjacency arrays, 0xFFFFFFFF =
+    // not known yet -- what lets the connect phase prune without evaluating a single distance (see ConnectArgs)
+    uint32_t *adjd0_mut, *adjd_up_mut;
     uint64_t *req_keys;         // hx_edge_key(layer, target, source)
     uint32_t *req_vals;         // bits of d(source, target)
     uint32_t *req_count;        // records reserved (may pass req_cap: see req_fail_base)
@@ -121,6 +124,13 @@ struct ConnectArgs {
     uint32_t count;
     uint32_t m;
     uint32_t *adj0_mut, *adj_up_mut;
+    // Edge distances kept beside the adjacency for the length of a build (optional, null = evaluate as before).  A prune
+    // needs d(x, n) for every neighbour n of the row's node x (select_simple, template.rs:614-621); each of them was
+    // computed when its edge was made -- by the insertion search of one endpoint, d being bit-symmetric -- so it is
+    // stored with the edge (0xFFFFFFFF = not known: rows that predate the build; evaluated once, then kept) and a
+    // prune becomes a sort of 33 keys instead of a gather of 32 vector rows (a third of a 16M x 256d build's
+    // sort + connect + remove time was those gathers, through the any-dimension distance loop at that).
+    uint32_t *adjd0_mut, *adjd_up_mut;
     uint64_t *out_keys;     // phase 2: removals hx_edge_key(layer, x, n); phase 3: refusals (same form)
     uint32_t *out_count;
     uint32_t out_cap;

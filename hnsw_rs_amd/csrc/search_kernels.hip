@@ -2371,9 +2371,12 @@ hx_insert_kernel(const DevView v, const InsertArgs a, const uint32_t slots_log2)
                     const uint32_t j = j0 + (uint32_t)lane;
                     const uint32_t id = j < m ? o_ids[(size_t)l * m + j] : HX_EMPTY_SLOT;
                     if (!a.emit_own) {
-                        uint32_t *row = l == 0 ? a.adj0_mut + (size_t)p * S
-                                               : a.adj_up_mut + ((size_t)v.upper_base[p] + l - 1) * S;
+                        const size_t at = l == 0 ? (size_t)p * S : ((size_t)v.upper_base[p] + l - 1) * S;
+                        uint32_t *row = (l == 0 ? a.adj0_mut : a.adj_up_mut) + at;
                         if (j < S) row[j] = id;
+                        uint32_t *rowd = l == 0 ? a.adjd0_mut : a.adjd_up_mut;
+                        if (rowd != nullptr && j < S)  // the edge's distance travels with it (ConnectArgs)
+                            rowd[at + j] = id != HX_EMPTY_SLOT ? __builtin_bit_cast(uint32_t, o_d[(size_t)l * m + j]) : 0xFFFFFFFFu;
                     }
                     if (id != HX_EMPTY_SLOT) {
                         const uint32_t db = __builtin_bit_cast(uint32_t, o_d[(size_t)l * m + j]);
@@ -2521,21 +2524,24 @@ hx_connect_kernel(const DevView v, const ConnectArgs a) {
         *a.status = HNSW_ERR_NODE_NOT_IN_GRAPH;  // a malformed record: never touch memory for it
         return;
     }
-    uint32_t *row = layer == 0 ? a.adj0_mut + (size_t)n * S
-                               : a.adj_up_mut + ((size_t)v.upper_base[n] + layer - 1) * S;
+    const size_t row_at = layer == 0 ? (size_t)n * S : ((size_t)v.upper_base[n] + layer - 1) * S;
+    uint32_t *row = (layer == 0 ? a.adj0_mut : a.adj_up_mut) + row_at;
+    uint32_t *rowd = layer == 0 ? a.adjd0_mut : a.adjd_up_mut;  // the edges' distances, or null
+    if (rowd != nullptr) rowd += row_at;
     constexpr int LPC = (KIND == HNSW_VEC_QUANT8) ? 2 : 1;
     constexpr int CHUNK = 64 / LPC;
     const int h = (LPC == 2) ? (lane & 1) : 0;
     const int cslot = lane / LPC;
     const bool first = (LPC == 1) || (h == 0);
 
-    uint32_t cur[RS];
+    uint32_t cur[RS], curd[RS];
     u64 hm[RS];
     uint32_t deg = 0;
 #pragma unroll
     for (int r = 0; r < RS; r++) {
         const uint32_t slot = 64u * r + (uint32_t)lane;
         cur[r] = slot < S ? row[slot] : HX_EMPTY_SLOT;
+        curd[r] = (rowd != nullptr && slot < S) ? rowd[slot] : 0xFFFFFFFFu;
         hm[r] = __ballot(cur[r] != HX_EMPTY_SLOT);
         deg += (uint32_t)__popcll(hm[r]);
     }
@@ -2543,15 +2549,29 @@ hx_connect_kernel(const DevView v, const ConnectArgs a) {
         uint32_t before = 0;               // (all reads of the row happened above)
 #pragma unroll
         for (int r = 0; r < RS; r++) {
-            if (cur[r] != HX_EMPTY_SLOT) row[before + (uint32_t)__popcll(hm[r] & ((1ull << lane) - 1))] = cur[r];
+            if (cur[r] != HX_EMPTY_SLOT) {
+                const uint32_t at = before + (uint32_t)__popcll(hm[r] & ((1ull << lane) - 1));
+                row[at] = cur[r];
+                if (rowd != nullptr) rowd[at] = curd[r];
+            }
             before += (uint32_t)__popcll(hm[r]);
         }
-        for (uint32_t j = lane; j < k; j += 64) row[deg + j] = (uint32_t)(a.keys[lo + j] & HX_EDGE_ID_MASK);
-        for (uint32_t j = deg + k + lane; j < S; j += 64) row[j] = HX_EMPTY_SLOT;
+        for (uint32_t j = lane; j < k; j += 64) {
+            row[deg + j] = (uint32_t)(a.keys[lo + j] & HX_EDGE_ID_MASK);
+            if (rowd != nullptr) rowd[deg + j] = a.vals[lo + j];  // d(source, n) = d(n, source)
+        }
+        for (uint32_t j = deg + k + lane; j < S; j += 64) {
+            row[j] = HX_EMPTY_SLOT;
+            if (rowd != nullptr) rowd[j] = 0xFFFFFFFFu;
+        }
         return;
     }
     // ---- prune: keep the `cap` nearest of existing ∪ sources ----
-    stage_row<KIND>(v, n, yq, lane);
+    // the node's own row is staged only when some existing neighbour's distance is not known yet
+    bool any_unknown = false;
+#pragma unroll
+    for (int r = 0; r < RS; r++) any_unknown |= __ballot(cur[r] != HX_EMPTY_SLOT && curd[r] == 0xFFFFFFFFu) != 0;
+    if (any_unknown) stage_row<KIND>(v, n, yq, lane);
     WaveList<RS> wl;
 #pragma unroll
     for (int r = 0; r < RS; r++) {
@@ -2563,18 +2583,26 @@ hx_connect_kernel(const DevView v, const ConnectArgs a) {
     wave_fence();
     for (uint32_t c0 = 0; c0 < S; c0 += CHUNK) {  // existing neighbours, CHUNK at a time
         const uint32_t slot = c0 + cslot;
-        uint32_t id = HX_EMPTY_SLOT;
+        uint32_t id = HX_EMPTY_SLOT, dbits = 0xFFFFFFFFu;
 #pragma unroll
         for (int r = 0; r < RS; r++) {
             const uint32_t t = (uint32_t)__shfl((int)cur[r], (int)(slot & 63));
-            if ((slot >> 6) == (uint32_t)r) id = t;
+            const uint32_t td = (uint32_t)__shfl((int)curd[r], (int)(slot & 63));
+            if ((slot >> 6) == (uint32_t)r) {
+                id = t;
+                dbits = td;
+            }
         }
         const bool act = slot < S && id < v.n_points;
         if (slot < S && id != HX_EMPTY_SLOT && id >= v.n_points) *a.status = HNSW_ERR_NODE_NOT_IN_GRAPH;
-        const float dist = dist_build<KIND, DS>(v, id, act, h, yq);
+        const bool need = act && dbits == 0xFFFFFFFFu;  // (an edge that predates the build: evaluated once, kept from here on)
+        if (__ballot(need) != 0) {
+            const float dist = dist_build<KIND, DS>(v, id, need, h, yq);
+            if (need) dbits = __builtin_bit_cast(uint32_t, dist);
+        }
         u64 key = KEY_INVALID;
         if (act && first) {
-            key = ((u64)__builtin_bit_cast(uint32_t, dist) << 32) | id;
+            key = ((u64)dbits << 32) | id;
             ekeys[slot] = key;
         }
         wl.merge(key, cap, perm, lane);
@@ -2587,7 +2615,10 @@ hx_connect_kernel(const DevView v, const ConnectArgs a) {
 #pragma unroll
     for (int r = 0; r < RS; r++) {
         const uint32_t slot = 64u * r + (uint32_t)lane;
-        if (slot < S) row[slot] = slot < wl.n_cur ? (uint32_t)wl.L[r] : HX_EMPTY_SLOT;
+        if (slot < S) {
+            row[slot] = slot < wl.n_cur ? (uint32_t)wl.L[r] : HX_EMPTY_SLOT;
+            if (rowd != nullptr) rowd[slot] = slot < wl.n_cur ? (uint32_t)(wl.L[r] >> 32) : 0xFFFFFFFFu;
+        }
     }
     // report what fell out: key > the last kept key (keys are distinct)
     const u64 lastk = wl.n_cur >= cap ? wl.last_key : KEY_INVALID;
@@ -2632,14 +2663,17 @@ hx_remove_kernel(const DevView v, const ConnectArgs a) {
         *a.status = HNSW_ERR_NODE_NOT_IN_GRAPH;
         return;
     }
-    uint32_t *row = layer == 0 ? a.adj0_mut + (size_t)x * S
-                               : a.adj_up_mut + ((size_t)v.upper_base[x] + layer - 1) * S;
-    uint32_t cur[RS];
+    const size_t row_at = layer == 0 ? (size_t)x * S : ((size_t)v.upper_base[x] + layer - 1) * S;
+    uint32_t *row = (layer == 0 ? a.adj0_mut : a.adj_up_mut) + row_at;
+    uint32_t *rowd = layer == 0 ? a.adjd0_mut : a.adjd_up_mut;  // the edges' distances move with their ids
+    if (rowd != nullptr) rowd += row_at;
+    uint32_t cur[RS], curd[RS];
     uint32_t deg = 0;
 #pragma unroll
     for (int r = 0; r < RS; r++) {
         const uint32_t slot = 64u * r + (uint32_t)lane;
         cur[r] = slot < S ? row[slot] : HX_EMPTY_SLOT;
+        curd[r] = (rowd != nullptr && slot < S) ? rowd[slot] : 0xFFFFFFFFu;
         deg += (uint32_t)__popcll(__ballot(cur[r] != HX_EMPTY_SLOT));
     }
     for (uint32_t j = 0; j < k; j++) {
@@ -2668,13 +2702,20 @@ hx_remove_kernel(const DevView v, const ConnectArgs a) {
 #pragma unroll
     for (int r = 0; r < RS; r++) {
         const u64 hm = __ballot(cur[r] != HX_EMPTY_SLOT);
-        if (cur[r] != HX_EMPTY_SLOT) row[before + (uint32_t)__popcll(hm & ((1ull << lane) - 1))] = cur[r];
+        if (cur[r] != HX_EMPTY_SLOT) {
+            const uint32_t at = before + (uint32_t)__popcll(hm & ((1ull << lane) - 1));
+            row[at] = cur[r];
+            if (rowd != nullptr) rowd[at] = curd[r];
+        }
         before += (uint32_t)__popcll(hm);
     }
 #pragma unroll
     for (int r = 0; r < RS; r++) {
         const uint32_t slot = 64u * r + (uint32_t)lane;
-        if (slot >= before && slot < S) row[slot] = HX_EMPTY_SLOT;
+        if (slot >= before && slot < S) {
+            row[slot] = HX_EMPTY_SLOT;
+            if (rowd != nullptr) rowd[slot] = 0xFFFFFFFFu;
+        }
     }
 }
 
