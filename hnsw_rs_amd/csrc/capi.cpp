@@ -267,6 +267,14 @@ int ensure_uploaded(hnsw_index *h) {
         if (rc != HNSW_OK) return rc;
         h->device = h->dev.device;
         h->n_uploads.fetch_add(1, std::memory_order_relaxed);
+        // searches above ef 320 take their visited set's second level from the device's stream-ordered pool, launch after
+        // launch: the pool keeps what is given back instead of returning it to the driver at every synchronisation
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, h->dev.device) == hipSuccess && pool != nullptr) {
+            uint64_t keep = 1ull << 30;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        (void)hipGetLastError();
     }
     hipError_t e = hipSetDevice(h->dev.device);
     if (e != hipSuccess) {
