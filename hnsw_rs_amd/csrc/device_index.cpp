@@ -325,7 +325,10 @@ bool DeviceIndex::append_point(const HostIndex &idx, NodeID id, const std::vecto
     const int fill[7] = {0, 0xFF, 0xFF, 0xFF, 0, 0xFF, 0};
     if (!pstream_ && hipStreamCreateWithFlags(&pstream_, hipStreamNonBlocking) != hipSuccess) return false;
     for (int i = 0; i < 7; i++)
-        if (need[i] && !grow(i, need[i], fill[i])) return false;  // (nothing written yet: the snapshot is merely stale)
+        if (need[i] && !grow(i, need[i], fill[i])) {
+            valid = false;  // (an array that did grow has moved: the view's pointers are no longer all good -- the next search uploads)
+            return false;
+        }
 
     // ---- staging: [descriptors | words] through one pinned buffer and one copy ----
     const size_t desc_bytes = (pieces.size() * sizeof(PatchDesc) + 255) & ~(size_t)255;
