@@ -2185,7 +2185,25 @@ int hnsw_set_device(hnsw_index *h, int device) {
     if (!h) return HNSW_ERR_ARG;
     std::lock_guard<std::mutex> g(h->mu);
     if (is_replica(h) && device != h->device) return reject_replica(h, "hnsw_set_device (a replica stays on the device it was received on)");
-    if (device != h->device) h->dev.release();
+    if (device != h->device) {
+        h->dev.release();
+        // a leaderless batch the coalescer keeps open was made ready for the old device (stream, device arena): retire
+        // it; the next caller opens one on the new device (no search may be in flight during this call)
+        Coalescer &co = h->co;
+        std::lock_guard<SpinLock> cg(co.mu);
+        for (size_t i = 0; i < co.open.size();) {
+            CoBatch *o = co.open[i];
+            uint64_t w = o->word.load(std::memory_order_acquire);
+            if ((w & CoBatch::COUNT) == 0 && !(w & CoBatch::CLOSED) &&
+                o->word.compare_exchange_strong(w, w | CoBatch::CLOSED, std::memory_order_acq_rel)) {
+                co.open.erase(co.open.begin() + i);
+                co.idle.push_back(o);
+            } else {
+                i++;
+            }
+        }
+        co.fast.store(nullptr, std::memory_order_release);
+    }
     h->device = device;
     return HNSW_OK;
 }

@@ -185,3 +185,28 @@ def test_insert_vec_with_overflowing_rows_and_inline_rows():
         assert index.insert_vec(qs[i], level=0) == orc.insert_vec(qs[i], 0)
         assert index.ann_by_vector(new[i], 5, 30) == [int(x) for x in orc.ann_by_vector(new[i], 5, 30)], "compact, step %d" % i
     assert_search_equal(index.search_batch(qs, 5, 40), orc.search_batch(qs, 5, 40), "overflow lists, compact, patched")
+
+
+def test_searching_threads_between_inserts():
+    """phases of concurrent one-query callers alternating with insert_vec calls (never at the same time: the contract of
+    include/hnsw_mi355x.h): the coalescer's batches outlive the snapshot's patches -- new points, a new top layer, a moved
+    entry point -- and every answer is the oracle's on the graph as it stands in that phase"""
+    d, m, n0 = 48, 8, 6000
+    vs = H.synth_rows(0, 0x5EED0001, 0, n0, d)
+    lv = O.draw_levels(n0, m, 13)
+    index = H.HNSW.new(m, 16, d, H.VEC_QUANT8).insert_bulk(vs, 4, False, levels=lv)
+    orc = oracle_from_product(index, vs, lv)
+    qs = H.synth_rows(0, 0x5EED0002, 0, 160, d)
+    new = H.synth_rows(0, 0x5EED0009, 0, 40, d)
+    index.upload()
+    up0 = index.stat("uploads")
+    for phase in range(8):
+        want = orc.search_batch(qs, 7, 40)
+        ids, counts, calls, _, _ = index.search_threads(qs, 7, 40, threads=12, seconds=0.05)
+        assert np.array_equal(ids, want[0]) and np.array_equal(counts, want[2]), "phase %d" % phase
+        for i in range(5):
+            v = new[phase * 5 + i]
+            level = index.nb_layers() if (phase == 3 and i == 0) else 0  # phase 3 opens a new top layer
+            assert index.insert_vec(v, level=level) == orc.insert_vec(v, level)
+    assert index.stat("uploads") == up0 and index.stat("patch_fallbacks") == 0
+    assert index.stat("coalesced_max_batch") > 1
