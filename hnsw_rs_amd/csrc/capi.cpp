@@ -146,7 +146,8 @@ struct hnsw_index {
     // build's algorithmic bytes -- and how long it and the connect phases ran
     struct BuildStats {
         uint64_t points = 0, batches = 0, rows_read = 0, adj_rows = 0, adj_ids = 0, records = 0, removals = 0;
-        double insert_kernel_s = 0, insert_phase_s = 0, connect_s = 0;
+        uint64_t rows_owned = 0, rows_received = 0, exchange_bytes = 0;  // sharded build, phases 2 / 3 by row ownership
+        double insert_kernel_s = 0, insert_phase_s = 0, connect_s = 0, exchange_s = 0, connect_kernel_s = 0;
     } build;
 };
 
@@ -1053,11 +1054,17 @@ void clamp_rows_to_cap(hx::HostIndex &host, std::vector<uint64_t> *restore) {
     }
 }
 
-// Sharded build (BASELINE configs[4]): every rank holds the full replica and runs phases 2 / 3 on it;
-// the insertion searches of a batch -- the expensive phase -- are split over the ranks, and what they
-// produce travels as edge records through ONE all-gather per batch (the caller's collective, RCCL in
-// production).  The record list carries the whole batch (own rows included, InsertArgs::emit_own), the
-// sort makes its order canonical, phases 2 / 3 are deterministic: the replicas stay identical.
+// Sharded build (BASELINE configs[4]): every rank holds the full replica.  The insertion searches of a batch are
+// split over the ranks by position, and what they produce travels as edge records through an all-gather (the
+// caller's collective, RCCL in production); the record list carries the whole batch (own rows included,
+// InsertArgs::emit_own) and its sort makes the order canonical.  Phases 2 / 3 are split by ROW: every rank sees
+// every record, the rank that owns a row (node id % world) appends / prunes / drops in it -- each row's outcome
+// depends on that row and its records alone, so the split changes nothing -- the removals phase 2 files are
+// all-gathered between the two phases, and the rows an owner changed travel to the other replicas as whole rows of
+// ids at the end of the batch (hx_pack_rows_kernel / hx_apply_rows_kernel).  Four collectives per batch (records;
+// removal counts + removals; row counts + rows -- the count exchanges are 64 B per rank and carry the rank's status,
+// so the ranks stop together), the replicas identical after each.  HNSW_MI355X_SHARD_CONNECT=0: phases 2 / 3 on
+// every rank in full, as before round 4 (one collective per batch).
 struct ShardCtx {
     uint32_t rank, world;
     unsigned char *d_send, *d_recv;  // one slot / world slots of slot_bytes
@@ -1070,8 +1077,15 @@ constexpr uint32_t SH_HEADER = 64, SH_FAILCAP = 1024, SH_BCAP = 32768;
 inline uint32_t shard_slot_records(uint32_t m, uint32_t world) {
     return ((SH_BCAP + world - 1) / world) * m * 4;  // both directions, 2 x slack for upper layers
 }
-inline uint64_t shard_slot_bytes(uint32_t m, uint32_t world) {
+inline uint64_t shard_record_bytes(uint32_t m, uint32_t world) {  // the records' part of a slot: [header][failed ids][keys][vals]
     return ((uint64_t)SH_HEADER + SH_FAILCAP * 4 + (uint64_t)shard_slot_records(m, world) * 12 + 255) & ~255ull;
+}
+// rows one rank may change in a batch (its share of the targets of every rank's records, plus the rows it drops from)
+inline uint32_t shard_slot_rows(uint32_t m, uint32_t world) { return 2 * shard_slot_records(m, world); }
+inline uint32_t shard_ship_slots(uint32_t m) { return hx::adj_stride(2ull * m, 32); }  // ids per shipped row: a layer-0 row
+inline uint64_t shard_slot_bytes(uint32_t m, uint32_t world) {
+    const uint64_t rows = (uint64_t)SH_HEADER + (uint64_t)shard_slot_rows(m, world) * (8 + 4ull * shard_ship_slots(m));
+    return (std::max(shard_record_bytes(m, world), rows) + 255) & ~255ull;
 }
 
 int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads, int verbose,
@@ -1173,17 +1187,93 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     }
     const uint32_t REF_CAP = 1u << 20;      // kept-last-edge records of the whole build
     const size_t temp_bytes = hx::sort_temp_bytes(REQ_CAP);
-    DevBuf dLevels, dIds, dOutIds, dOutD, dStatus, dCnt, dKeyA, dKeyB, dValA, dValB, dTemp, dRef, dRead;
+    const uint64_t REC_BYTES = sh ? shard_record_bytes(m, W) : 0;
+    // phases 2 / 3 split by row ownership (ShardCtx above)
+    static const bool shard_connect_on = !(getenv("HNSW_MI355X_SHARD_CONNECT") && atoi(getenv("HNSW_MI355X_SHARD_CONNECT")) == 0);
+    const bool own_rows = sh && W > 1 && shard_connect_on;
+    const uint32_t CHG_CAP = own_rows ? shard_slot_rows(m, W) : 0, SHIP = shard_ship_slots(m);
+    const uint64_t SHIP_UNIT = 8 + 4ull * SHIP;
+    if (own_rows && (v.S0 > SHIP || v.S1 > SHIP)) {
+        set_error("sharded build: adjacency rows of %u / %u slots, exchange entries of %u", v.S0, v.S1, SHIP);
+        return HNSW_ERR_ARG;
+    }
+    // the file of changed rows: HX_CHG_LISTS lists (ConnectArgs), each with room for twice its even share
+    const uint32_t CHG_LIST_CAP = own_rows ? 2 * ((CHG_CAP + hx::HX_CHG_LISTS - 1) / hx::HX_CHG_LISTS) : 0;
+    DevBuf dLevels, dIds, dOutIds, dOutD, dStatus, dCnt, dKeyA, dKeyB, dValA, dValB, dTemp, dRef, dRead, dChg, dChgCnt;
+    if (own_rows && ((rc = dChg.alloc((size_t)CHG_LIST_CAP * hx::HX_CHG_LISTS * 8)) || (rc = dChgCnt.alloc(hx::HX_CHG_LISTS * 4)))) return rc;
+    // One variable-size exchange: 64 B per rank first ([count, status]: every rank learns every count and stops
+    // with the others when one of them failed), then the largest count's worth of bytes per rank.  `d_src` is copied
+    // behind the header (nullptr: the data is in the slot already).  Rank r's data: d_recv + r * stride + SH_HEADER.
+    std::vector<uint32_t> x_counts(W);
+    uint64_t x_stride = 0;
+    double t_exchange = 0;
+    uint64_t x_bytes = 0;
+    auto exchange = [&](uint32_t count, uint64_t unit, int32_t status, const void *d_src, const char *what) -> int {
+        const auto tx0 = std::chrono::steady_clock::now();
+        if ((uint64_t)SH_HEADER + count * unit > sh->slot_bytes && status == 0) status = HNSW_ERR_OVERFLOW;
+        uint32_t hdr[SH_HEADER / 4] = {0};
+        hdr[0] = status ? 0 : count;
+        hdr[1] = (uint32_t)status;
+        HIP_TRY(hipMemcpy(sh->d_send, hdr, SH_HEADER, hipMemcpyHostToDevice));
+        if (d_src && hdr[0])
+            HIP_TRY(hipMemcpyAsync(sh->d_send + SH_HEADER, d_src, hdr[0] * unit, hipMemcpyDeviceToDevice, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        int r = sh->allgather(sh->ctx, SH_HEADER);
+        if (r != 0) {
+            set_error("sharded build: the all-gather callback failed (%d) on the %s counts", r, what);
+            return HNSW_ERR_RCCL;
+        }
+        std::vector<uint32_t> all((size_t)W * SH_HEADER / 4);
+        HIP_TRY(hipMemcpy(all.data(), sh->d_recv, (size_t)W * SH_HEADER, hipMemcpyDeviceToHost));
+        uint32_t maxc = 0;
+        for (uint32_t k = 0; k < W; k++) {
+            if (all[k * (SH_HEADER / 4) + 1] != 0) {
+                set_error("sharded build: rank %u reported status %d in the %s phase", k, (int)all[k * (SH_HEADER / 4) + 1], what);
+                return (int)all[k * (SH_HEADER / 4) + 1];
+            }
+            x_counts[k] = all[k * (SH_HEADER / 4)];
+            maxc = std::max(maxc, x_counts[k]);
+        }
+        x_stride = (SH_HEADER + maxc * unit + 63) & ~63ull;
+        if (x_stride > sh->slot_bytes) {  // cannot happen with honest peers (each checked its own count above)
+            set_error("sharded build: a rank announced %u %s, beyond the slot", maxc, what);
+            return HNSW_ERR_OVERFLOW;
+        }
+        if (maxc) {
+            r = sh->allgather(sh->ctx, x_stride);
+            if (r != 0) {
+                set_error("sharded build: the all-gather callback failed (%d) on the %s", r, what);
+                return HNSW_ERR_RCCL;
+            }
+            x_bytes += x_stride * W;
+        }
+        t_exchange += std::chrono::duration<double>(std::chrono::steady_clock::now() - tx0).count();
+        return HNSW_OK;
+    };
     struct EvPair {  // the insert kernel's launches are timed with HIP events on their stream
         hipEvent_t a = nullptr, b = nullptr;
         ~EvPair() {
             if (a) (void)hipEventDestroy(a);
             if (b) (void)hipEventDestroy(b);
         }
-    } ev;
+    } ev, ev_conn, ev_rem;
     HIP_TRY(hipEventCreate(&ev.a));
     HIP_TRY(hipEventCreate(&ev.b));
-    double t_kernel_ms = 0;
+    HIP_TRY(hipEventCreate(&ev_conn.a));
+    HIP_TRY(hipEventCreate(&ev_conn.b));
+    HIP_TRY(hipEventCreate(&ev_rem.a));
+    HIP_TRY(hipEventCreate(&ev_rem.b));
+    double t_kernel_ms = 0, t_conn_kernel_ms = 0;
+    bool rem_pending = false;
+    auto collect_remove_time = [&]() -> int {  // the drop kernel of the previous batch (nothing waits for it in-batch)
+        if (!rem_pending) return HNSW_OK;
+        HIP_TRY(hipEventSynchronize(ev_rem.b));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ev_rem.a, ev_rem.b));
+        t_conn_kernel_ms += ms;
+        rem_pending = false;
+        return HNSW_OK;
+    };
     if ((rc = dRead.alloc(32))) return rc;
     HIP_TRY(hipMemset(dRead.p, 0, 32));
     if ((rc = dLevels.alloc(host.len())) || (rc = dIds.alloc(BMAX * 4)) ||
@@ -1217,7 +1307,7 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     std::vector<NodeID> failed;
     uint64_t connected = n_before + pos;
     double t_ins = 0, t_conn = 0;
-    size_t n_batches = 0, n_req = 0, n_rem = 0, n_again = 0;
+    size_t n_batches = 0, n_req = 0, n_rem = 0, n_again = 0, n_shipped = 0, n_owned = 0;
     uint32_t counts[4];
     // the capacity of the new points' host rows (one small allocation each) is reserved by other threads while the
     // GPU runs the batches: nothing touches the host graph until the read-back below
@@ -1240,10 +1330,12 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
                                           std::min<uint64_t>(std::min<uint64_t>(BMAX, h->build_batch_max), std::max<uint64_t>(64, connected / h->build_batch_div)));
         const NodeID *batch = &order[pos];
         auto t0 = std::chrono::steady_clock::now();
+        if ((rc = collect_remove_time())) return rc;
         // this rank's slice of the batch (everything when not sharded)
         const size_t s_lo = sh ? B * sh->rank / W : 0, s_hi = sh ? B * (sh->rank + 1) / W : B, nb = s_hi - s_lo;
         if (nb) HIP_TRY(hipMemcpy(dIds.p, batch + s_lo, nb * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemset(dCnt.p, 0, 8));  // requests, removals
+        if (own_rows) HIP_TRY(hipMemset(dChgCnt.p, 0, hx::HX_CHG_LISTS * 4));  // rows this rank changed
         // ---- phase 1: searches + heuristic, own rows, requests ----
         hx::InsertArgs a{};
         a.point_ids = dIds.as<uint32_t>();
@@ -1366,14 +1458,14 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
             if (nf) HIP_TRY(hipMemcpy(fail_ids, myfail.data(), nf * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipDeviceSynchronize());
             // ---- the one exchange of the batch ----
-            rc = sh->allgather(sh->ctx, sh->slot_bytes);
+            rc = sh->allgather(sh->ctx, REC_BYTES);
             if (rc != 0) {
                 set_error("sharded build: the all-gather callback failed (%d)", rc);
                 return HNSW_ERR_RCCL;
             }
             // concatenate the slots' records; every rank sees the same list
             for (uint32_t r = 0; r < W; r++) {
-                const unsigned char *rs = sh->d_recv + (size_t)r * sh->slot_bytes;
+                const unsigned char *rs = sh->d_recv + (size_t)r * REC_BYTES;
                 uint32_t rh[2];
                 HIP_TRY(hipMemcpy(rh, rs, 8, hipMemcpyDeviceToHost));
                 if (rh[0] > SLOT_REC || rh[1] > SH_FAILCAP || nreq + rh[0] > REQ_CAP) {
@@ -1412,15 +1504,49 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         ca.out_count = cnt + 1;
         ca.out_cap = REQ_CAP;
         ca.status = reinterpret_cast<int32_t *>(cnt + 3);
+        if (own_rows) {
+            ca.own_rank = sh->rank;
+            ca.own_world = W;
+            ca.chg_keys = dChg.as<uint64_t>();
+            ca.chg_count = dChgCnt.as<uint32_t>();
+            ca.chg_cap = CHG_LIST_CAP;
+        }
+        HIP_TRY(hipEventRecord(ev_conn.a, nullptr));
         rc = hx::launch_connect(v, ca, nullptr);
         if (rc != HNSW_OK) return rc;
+        HIP_TRY(hipEventRecord(ev_conn.b, nullptr));
         HIP_TRY(hipMemcpy(counts, dCnt.p, 16, hipMemcpyDeviceToHost));
-        if (counts[3] != 0) {
+        {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, ev_conn.a, ev_conn.b));
+            t_conn_kernel_ms += ms;
+        }
+        if (counts[3] != 0 && !own_rows) {
             set_error("on-device build: connect kernel reported status %d in batch %zu", (int)counts[3], n_batches);
             return (int)counts[3];
         }
+        uint32_t nrem = counts[1];
+        if (own_rows) {
+            // the removals of every owner's prunes, in every rank's list (phase 3 filters by the owner of the row
+            // that loses the edge); the sort below makes the order canonical
+            const int32_t st = counts[3] != 0 ? (int32_t)counts[3] : (nrem > REQ_CAP ? HNSW_ERR_OVERFLOW : 0);
+            rc = exchange(st ? 0 : nrem, 8, st, dKeyA.p, "removals");
+            if (rc != HNSW_OK) return rc;
+            uint64_t tot = 0;
+            for (uint32_t r = 0; r < W; r++) tot += x_counts[r];
+            if (tot > REQ_CAP) {
+                set_error("sharded build: %llu removals in one batch, room for %u", (unsigned long long)tot, REQ_CAP);
+                return HNSW_ERR_OVERFLOW;
+            }
+            nrem = 0;
+            for (uint32_t r = 0; r < W; r++) {
+                if (x_counts[r])
+                    HIP_TRY(hipMemcpyAsync(dKeyA.as<uint64_t>() + nrem, sh->d_recv + (size_t)r * x_stride + SH_HEADER,
+                                           (size_t)x_counts[r] * 8, hipMemcpyDeviceToDevice, nullptr));
+                nrem += x_counts[r];
+            }
+        }
         // ---- phase 3: group the removals by row, drop the reverse edges ----
-        const uint32_t nrem = counts[1];
         rc = hx::sort_edge_keys(dTemp.p, temp_bytes, dKeyA.as<uint64_t>(), dKeyB.as<uint64_t>(), nrem, L, nullptr);
         if (rc != HNSW_OK) return rc;
         ca.keys = dKeyB.as<uint64_t>();
@@ -1429,8 +1555,44 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         ca.out_keys = dRef.as<uint64_t>();
         ca.out_count = cnt + 2;
         ca.out_cap = REF_CAP;
+        HIP_TRY(hipEventRecord(ev_rem.a, nullptr));
         rc = hx::launch_remove(v, ca, nullptr);
         if (rc != HNSW_OK) return rc;
+        HIP_TRY(hipEventRecord(ev_rem.b, nullptr));
+        rem_pending = true;
+        if (own_rows) {
+            // ---- the rows this rank changed, to the other replicas ----
+            uint32_t c4[4], lists[hx::HX_CHG_LISTS];
+            HIP_TRY(hipMemcpy(lists, dChgCnt.p, sizeof(lists), hipMemcpyDeviceToHost));  // synchronises
+            HIP_TRY(hipMemcpy(c4, dCnt.p, 16, hipMemcpyDeviceToHost));
+            int32_t st = (int32_t)c4[3];
+            uint64_t nchg64 = 0;
+            uint32_t longest = 0;
+            for (uint32_t c : lists) {
+                nchg64 += c;
+                longest = std::max(longest, c);
+            }
+            if (st == 0 && (longest > CHG_LIST_CAP || nchg64 > CHG_CAP || (uint64_t)SH_HEADER + nchg64 * SHIP_UNIT > sh->slot_bytes))
+                st = HNSW_ERR_OVERFLOW;
+            const uint32_t nchg = st ? 0 : (uint32_t)nchg64;
+            if (st == 0) {
+                rc = hx::launch_pack_rows(v, h->dev.adj0_mut(), h->dev.adj_up_mut(), dChg.as<uint64_t>(), dChgCnt.as<uint32_t>(),
+                                          CHG_LIST_CAP, longest, SHIP, sh->d_send + SH_HEADER, nullptr);
+                if (rc != HNSW_OK) st = rc;
+            }
+            rc = exchange(st ? 0 : nchg, SHIP_UNIT, st, nullptr, "changed rows");
+            if (rc != HNSW_OK) return rc;
+            n_owned += nchg;
+            for (uint32_t r = 0; r < W; r++) {
+                if (r == sh->rank || x_counts[r] == 0) continue;
+                rc = hx::launch_apply_rows(v, h->dev.adj0_mut(), h->dev.adj_up_mut(), sh->d_recv + (size_t)r * x_stride + SH_HEADER,
+                                           x_counts[r], SHIP, reinterpret_cast<int32_t *>(cnt + 3), nullptr);
+                if (rc != HNSW_OK) return rc;
+                n_shipped += x_counts[r];
+            }
+            // the receive buffer is read by those launches: they finish before the next batch's exchange overwrites it
+            HIP_TRY(hipDeviceSynchronize());
+        }
         if (verbose) HIP_TRY(hipDeviceSynchronize());  // only to attribute the time
         auto t2 = std::chrono::steady_clock::now();
         t_ins += std::chrono::duration<double>(t1 - t0).count();
@@ -1444,6 +1606,7 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
             fprintf(stderr, "\rBuilding HNSW index on the GPU %zu/%zu", pos, order.size());
     }
 
+    if ((rc = collect_remove_time())) return rc;
     {  // what the build read and how long its kernels ran (hnsw_get_stat "build_*")
         unsigned long long rd[4] = {0, 0, 0, 0};
         HIP_TRY(hipMemcpy(rd, dRead.p, 32, hipMemcpyDeviceToHost));
@@ -1456,8 +1619,13 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         bs.records += n_req;
         bs.removals += n_rem;
         bs.insert_kernel_s += t_kernel_ms * 1e-3;
+        bs.connect_kernel_s += t_conn_kernel_ms * 1e-3;
         bs.insert_phase_s += t_ins;
         bs.connect_s += t_conn;
+        bs.rows_owned += n_owned;
+        bs.rows_received += n_shipped;
+        bs.exchange_bytes += x_bytes;
+        bs.exchange_s += t_exchange;
     }
     // ---- the host graph from the device arrays ----
     if (row_reserve.t.joinable()) row_reserve.t.join();
@@ -1469,6 +1637,21 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
     }
     std::vector<uint64_t> refusals(counts[2]);
     if (counts[2]) HIP_TRY(hipMemcpy(refusals.data(), dRef.p, (size_t)counts[2] * 8, hipMemcpyDeviceToHost));
+    if (own_rows) {  // every owner's kept-last-edge records, on every rank (the host restores the mirror edges below)
+        rc = exchange(counts[2], 8, 0, dRef.p, "kept-last-edge records");
+        if (rc != HNSW_OK) return rc;
+        refusals.clear();
+        for (uint32_t r = 0; r < W; r++) {
+            if (x_counts[r] == 0) continue;
+            const size_t at = refusals.size();
+            refusals.resize(at + x_counts[r]);
+            HIP_TRY(hipMemcpy(refusals.data() + at, sh->d_recv + (size_t)r * x_stride + SH_HEADER, (size_t)x_counts[r] * 8,
+                              hipMemcpyDeviceToHost));
+        }
+        if (verbose)
+            fprintf(stderr, "\nsharded build, rank %u of %u: phases 2 / 3 on the rows it owns; %zu rows received, %.1f MB through the "
+                            "variable-size exchanges in %.2f s\n", sh->rank, W, n_shipped, x_bytes / 1e6, t_exchange);
+    }
     for (int pass = 0; pass < 2; pass++) {
         std::vector<std::vector<NodeID>> &rowsv = pass == 0 ? host.adj0 : host.adj_up;
         const uint32_t S = pass == 0 ? v.S0 : v.S1;
@@ -2286,6 +2469,11 @@ int hnsw_get_stat(const hnsw_index *h, const char *key, uint64_t *out) {
         else if (!strcmp(k, "insert_kernel_us")) *out = (uint64_t)(bs.insert_kernel_s * 1e6);
         else if (!strcmp(k, "insert_phase_us")) *out = (uint64_t)(bs.insert_phase_s * 1e6);
         else if (!strcmp(k, "connect_us")) *out = (uint64_t)(bs.connect_s * 1e6);
+        else if (!strcmp(k, "connect_kernel_us")) *out = (uint64_t)(bs.connect_kernel_s * 1e6);
+        else if (!strcmp(k, "rows_owned")) *out = bs.rows_owned;
+        else if (!strcmp(k, "rows_received")) *out = bs.rows_received;
+        else if (!strcmp(k, "exchange_bytes")) *out = bs.exchange_bytes;
+        else if (!strcmp(k, "exchange_us")) *out = (uint64_t)(bs.exchange_s * 1e6);
         else {
             set_error("unknown statistic %s", key);
             return HNSW_ERR_ARG;

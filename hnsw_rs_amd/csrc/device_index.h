@@ -135,7 +135,27 @@ struct ConnectArgs {
     uint32_t *out_count;
     uint32_t out_cap;
     int32_t *status;        // single word: set when `out` is full or a record is malformed
+    // Sharded build (round 4): with own_world > 1 a wave handles only the rows whose node id % own_world == own_rank --
+    // every rank sees every record, each row has ONE owner that appends / prunes / drops -- and files the row in
+    // chg_keys (hx_edge_key(layer, node, 0); duplicates allowed) so that its new contents can be shipped to the other
+    // replicas (hx_pack_rows_kernel / hx_apply_rows_kernel, patch.hip).  The file is HX_CHG_LISTS lists of chg_cap
+    // keys each with a counter each, chosen by the workgroup's index: millions of appends per batch through ONE
+    // counter cost as much as the connect itself.  own_world <= 1: every row, nothing filed.
+    uint32_t own_rank, own_world;
+    uint64_t *chg_keys;   // [HX_CHG_LISTS][chg_cap]
+    uint32_t *chg_count;  // [HX_CHG_LISTS]
+    uint32_t chg_cap;
 };
+constexpr uint32_t HX_CHG_LISTS = 64;
+
+// rows that changed on their owner, packed for the exchange: entry i = [key u64][ship_slots ids u32], and back.
+// `keys` / `counts`: the HX_CHG_LISTS lists of list_cap keys of ConnectArgs; max_count = the longest list (the host
+// has read the counters); the entries leave in list order, sum(counts) of them.
+int launch_pack_rows(const DevView &v, const uint32_t *adj0, const uint32_t *adj_up, const uint64_t *keys,
+                     const uint32_t *counts, uint32_t list_cap, uint32_t max_count, uint32_t ship_slots, unsigned char *out,
+                     hipStream_t stream);
+int launch_apply_rows(const DevView &v, uint32_t *adj0, uint32_t *adj_up, const unsigned char *entries, uint32_t n,
+                      uint32_t ship_slots, int32_t *status, hipStream_t stream);
 
 // device radix sorts of the edge records (build_sort.hip, rocPRIM)
 size_t sort_temp_bytes(uint32_t max_n);

@@ -2524,6 +2524,16 @@ hx_connect_kernel(const DevView v, const ConnectArgs a) {
         *a.status = HNSW_ERR_NODE_NOT_IN_GRAPH;  // a malformed record: never touch memory for it
         return;
     }
+    if (a.own_world > 1) {  // sharded build: this row has ONE owner among the ranks
+        if (n % a.own_world != a.own_rank) return;
+        if (lane == 0) {     // its new contents will travel to the other replicas (64 lists: one counter would serialise)
+            const uint32_t seg = blockIdx.x & (HX_CHG_LISTS - 1), at = atomicAdd(a.chg_count + seg, 1u);
+            if (at < a.chg_cap)
+                a.chg_keys[(size_t)seg * a.chg_cap + at] = hx_edge_key(layer, n, 0);
+            else
+                *a.status = HNSW_ERR_OVERFLOW;
+        }
+    }
     const size_t row_at = layer == 0 ? (size_t)n * S : ((size_t)v.upper_base[n] + layer - 1) * S;
     uint32_t *row = (layer == 0 ? a.adj0_mut : a.adj_up_mut) + row_at;
     uint32_t *rowd = layer == 0 ? a.adjd0_mut : a.adjd_up_mut;  // the edges' distances, or null
@@ -2662,6 +2672,16 @@ hx_remove_kernel(const DevView v, const ConnectArgs a) {
     if (x >= v.n_points || layer >= v.nb_layers || (layer > 0 && v.upper_base[x] == HX_EMPTY_SLOT) || S > 64u * RS) {
         *a.status = HNSW_ERR_NODE_NOT_IN_GRAPH;
         return;
+    }
+    if (a.own_world > 1) {  // sharded build: x's row is dropped from by its owner only, and shipped afterwards
+        if (x % a.own_world != a.own_rank) return;
+        if (lane == 0) {
+            const uint32_t seg = blockIdx.x & (HX_CHG_LISTS - 1), at = atomicAdd(a.chg_count + seg, 1u);
+            if (at < a.chg_cap)
+                a.chg_keys[(size_t)seg * a.chg_cap + at] = hx_edge_key(layer, x, 0);
+            else
+                *a.status = HNSW_ERR_OVERFLOW;
+        }
     }
     const size_t row_at = layer == 0 ? (size_t)x * S : ((size_t)v.upper_base[x] + layer - 1) * S;
     uint32_t *row = (layer == 0 ? a.adj0_mut : a.adj_up_mut) + row_at;

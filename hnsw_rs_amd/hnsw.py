@@ -172,8 +172,9 @@ class HNSW:
     def insert_bulk_sharded(self, vectors, nb_threads, verbose, levels=None, group=None, device=None):
         """The on-device build sharded over the ranks of a torch.distributed group (BASELINE configs[4]):
         every rank passes the same vectors / levels and ends with an identical replica; the insertion
-        searches of each batch are split over the ranks and their edge records are exchanged with one
-        all-gather per batch (RCCL when the group's backend is nccl; staged through the host for gloo)."""
+        searches of each batch are split over the ranks by position, the connect / prune / drop phases by row
+        ownership; edge records, removals and changed rows travel through all-gathers of the size the batch needs
+        (RCCL when the group's backend is nccl; staged through the host for gloo)."""
         import torch
         import torch.distributed as dist
         from ._lib import ALLGATHER_FN
@@ -187,15 +188,16 @@ class HNSW:
 
         def allgather(_ctx, nbytes):
             try:
-                if nbytes != slot:
+                if nbytes > slot or nbytes <= 0:
                     return 1
+                # the first nbytes of every rank's send buffer, rank r's at r * nbytes of the receive buffer
                 if on_device:
-                    dist.all_gather_into_tensor(recv, send, group=group)
+                    dist.all_gather_into_tensor(recv[: world * nbytes], send[:nbytes], group=group)
                     torch.cuda.synchronize(dev)
                 else:  # gloo: CPU tensors
-                    parts = [torch.empty(slot, dtype=torch.uint8) for _ in range(world)]
-                    dist.all_gather(parts, send.cpu(), group=group)
-                    recv.copy_(torch.cat(parts))
+                    parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+                    dist.all_gather(parts, send[:nbytes].cpu(), group=group)
+                    recv[: world * nbytes].copy_(torch.cat(parts))
                     torch.cuda.synchronize(dev)
                 return 0
             except Exception as e:  # never unwind through the C frames

@@ -121,12 +121,15 @@ int hnsw_insert_bulk_device(hnsw_index *h, const float *rows, uint64_t n, uint32
                             int verbose, const uint8_t *levels);
 /* The on-device build sharded over the GPUs of a node (BASELINE configs[4]): every rank calls this with
  * the SAME rows / levels on its own replica.  The insertion searches of each batch are split over the
- * ranks; what they produce travels as edge records through one all-gather per batch, after which every
- * rank applies the same records to its replica (connect / prune / remove are deterministic, so the
- * replicas stay identical).  The collective is the caller's: d_send (one slot) and d_recv (world slots)
- * are device buffers of hnsw_sharded_slot_bytes() per slot, and `allgather(ctx, bytes_per_rank)` must
- * all-gather d_send into d_recv across the ranks and return 0 once d_recv is complete (RCCL through
- * torch.distributed in hnsw_rs_amd/hnsw.py).  The library has synchronised the device before it calls. */
+ * ranks by position and what they produce travels as edge records through an all-gather; the connect / prune /
+ * drop phases are split by row ownership (node id % world: a row's outcome depends on that row and its records
+ * alone), the removals and the rows each owner changed travelling through further all-gathers of the size the
+ * batch needs; the replicas are identical after every batch.  The collective is the caller's: d_send (one slot)
+ * and d_recv (world slots) are device buffers of hnsw_sharded_slot_bytes() per slot, and
+ * `allgather(ctx, bytes_per_rank)` (bytes_per_rank <= the slot size, a multiple of 64) must all-gather the FIRST
+ * bytes_per_rank bytes of every rank's d_send into d_recv, rank r's at offset r * bytes_per_rank, and return 0
+ * once d_recv is complete (RCCL through torch.distributed in hnsw_rs_amd/hnsw.py).  The library has synchronised
+ * the device before it calls.  Every rank makes the same sequence of calls with the same sizes. */
 typedef int (*hnsw_allgather_fn)(void *ctx, uint64_t bytes_per_rank);
 uint64_t hnsw_sharded_slot_bytes(const hnsw_index *h, uint32_t world);
 int hnsw_insert_bulk_sharded(hnsw_index *h, const float *rows, uint64_t n, uint32_t nb_threads, int verbose,
@@ -280,7 +283,10 @@ int hnsw_set_option(hnsw_index *h, const char *key, int64_t value);
  * insertion searches and the heuristic read: distance evaluations + staged rows), "build_adj_rows" / "build_adj_ids"
  * (adjacency rows read and the ids in them), "build_records" / "build_removals" (edge records filed, reverse edges
  * dropped), "build_insert_kernel_us" (hx_insert_kernel, HIP events), "build_insert_phase_us" / "build_connect_us"
- * (host clock: phase 1 with its copies, sort + connect + remove) */
+ * (host clock: phase 1 with its copies, sort + connect + remove), "build_connect_kernel_us" (hx_connect_kernel +
+ * hx_remove_kernel, HIP events), and for the sharded build "build_rows_owned" /
+ * "build_rows_received" (rows this rank changed as their owner and shipped; rows it received from the other owners),
+ * "build_exchange_bytes" / "build_exchange_us" (the variable-size all-gathers: bytes received, host clock) */
 int hnsw_get_stat(const hnsw_index *h, const char *key, uint64_t *out);
 
 /* ---- replication of the HBM snapshot over the GPUs of a node ----------------------------------- */

@@ -230,20 +230,30 @@ def _sharded_worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_sharded_device_build_at_256d(tmp_path):
+def test_sharded_device_build_at_256d(tmp_path, monkeypatch):
     """configs[4]: points sharded over two ranks, edge records all-gathered per batch; both replicas end
-    identical (two ranks on this one GPU, gloo rendezvous: only the exchange differs from an 8-GPU run)"""
+    identical (two ranks on this one GPU, gloo rendezvous: only the exchange differs from an 8-GPU run).
+    Phases 2 / 3 split by row ownership (the default) and run in full on every rank (HNSW_MI355X_SHARD_CONNECT=0)
+    leave the same graph."""
     import socket
     import torch.multiprocessing as mp
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    for k in r0.files:
-        assert np.array_equal(r0[k], r1[k]), k
-    assert r0["recall"][0] > 0.97
+    graphs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HNSW_MI355X_SHARD_CONNECT", mode)  # read once per process: the workers are new ones
+        out = tmp_path / ("mode" + mode)
+        out.mkdir()
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_sharded_worker, args=(2, port, str(out)), nprocs=2, join=True)
+        r0, r1 = np.load(out / "rank0.npz"), np.load(out / "rank1.npz")
+        for k in r0.files:
+            assert np.array_equal(r0[k], r1[k]), (mode, k)
+        assert r0["recall"][0] > 0.97
+        graphs.append(r0)
+    for k in graphs[0].files:
+        assert np.array_equal(graphs[0][k], graphs[1][k]), k
 
 
 @pytest.mark.parametrize("n,d", [(20000, 100), (9000, 128), (6000, 768), (5000, 36)])

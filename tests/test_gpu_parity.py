@@ -573,24 +573,36 @@ def _sharded_build_worker(rank, world, port, outdir):
     got, _, _, _ = idx.search_batch(qs, 10, 64)
     out["recall"] = np.array([sum(len(set(a) & set(b)) for a, b in zip(got.tolist(), truth.tolist())) / 1280.0])
     out["compliant"] = np.array([1 if idx.assert_param_compliance() else 0])
+    # phases 2 / 3 by row ownership: what this rank changed as an owner, what it received from the others
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
+    np.save(os.path.join(outdir, "stats%d.npy" % rank),
+            np.array([idx.stat("build_rows_owned"), idx.stat("build_rows_received"), idx.stat("build_exchange_bytes")]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_device_build_two_ranks(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_device_build_two_ranks(tmp_path, world):
+    """world 3: the row owners (id % 3) and the position slices of a batch do not line up anywhere"""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_sharded_build_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    assert sorted(r0.files) == sorted(r1.files)
-    for k in r0.files:  # identical replicas, edge for edge
-        assert np.array_equal(r0[k], r1[k]), k
+    mp.spawn(_sharded_build_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    for r in range(1, world):
+        r1 = np.load(tmp_path / ("rank%d.npz" % r))
+        assert sorted(r0.files) == sorted(r1.files)
+        for k in r0.files:  # identical replicas, edge for edge
+            assert np.array_equal(r0[k], r1[k]), (r, k)
     assert r0["recall"][0] > 0.97 and r0["compliant"][0] == 1
+    # every rank connected / pruned only the rows it owns and received the others: the rows owned sum to the rows
+    # received by any one rank plus its own
+    st = np.stack([np.load(tmp_path / ("stats%d.npy" % r)) for r in range(world)])
+    assert (st[:, 0] > 0).all() and (st[:, 1] > 0).all() and (st[:, 2] > 0).all(), st
+    assert all(int(st[:, 0].sum()) == int(st[r, 0] + st[r, 1]) for r in range(world)), st
     # and the same graph as the single-GPU on-device build of the same input: the sharding only
     # changes who runs which search, and the searches of a batch do not depend on each other
     n, d, m = 20000, 100, 16
