@@ -259,8 +259,9 @@ def get_index(c, kind_name):
             c.build_info = {"seconds": round(build_s, 3), "points_per_s": round(a.n_points / build_s, 1),
                             "row_generation_seconds": round(gen_s, 1), "layers": index.nb_layers(),
                             "form": ("host build" if a.cpu_build else
-                                     "on-device build, insertion searches sharded over %d rank(s), one RCCL all-gather of "
-                                     "edge records per batch (insert_bulk_sharded)" % c.world if sharded_build else
+                                     "on-device build, insertion searches sharded over %d rank(s) by position, connect / prune / drop by row "
+                                     "ownership; edge records, removals and changed rows all-gathered over RCCL per batch "
+                                     "(insert_bulk_sharded)" % c.world if sharded_build else
                                      "on-device build on one GPU (insert_bulk_device)"),
                             "host_threads": c.build_threads}
             if not a.cpu_build:
@@ -838,15 +839,15 @@ def main():
             sharded = "insert_bulk_sharded" in bi["form"]
             out["metric"] = ("points/sec inserted, index build %d x %dd fp32 (BASELINE configs[4]: on-device insert / "
                              "search_layer; %s; recall@10 of the built index reported)" % (
-                                 N, d, ("insertion searches sharded over %d ranks, one RCCL all-gather of the new edge records "
-                                        "per batch" % world) if sharded else
+                                 N, d, ("insertion searches sharded over %d ranks, connect / prune / drop by row ownership, edge records / "
+                                        "removals / changed rows all-gathered over RCCL per batch" % world) if sharded else
                                  "ONE GPU, insert_bulk_device: the sharded path (insert_bulk_sharded, RCCL all-gather) was NOT "
                                  "exercised by this run"))
             out["value"], out["unit"] = bi["points_per_s"], "points/s"
             out["steps"], out["warmup"], out["ms_per_step"] = 1, 0, round(bi["seconds"] * 1e3, 3)
             out["scaling"] = "strong"
             out["config"]["parallelism"] = (("every rank holds a replica; insertion searches of each batch split over %d GPUs, "
-                                             "edge records all-gathered over RCCL" % world) if sharded else
+                                             "connect / prune / drop by row ownership, records / removals / changed rows all-gathered over RCCL" % world) if sharded else
                                             "one GPU, no ranks, no collective (the build ran as %s)" % bi["form"])
             # the roofline of the headline value's dominant kernel (hx_insert_kernel) and the CPU build beside it;
             # `roofline` / `cpu_baseline` above describe the SEARCH on the index this run built
