@@ -401,7 +401,7 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
     # HBM traffic comes from separate rocprofv3 PMC passes (scripts/profile.sh) and is only quoted while
     # the kernels it was measured on are the ones running now (hash of the kernel sources)
-    traffic, traffic_from, sq = None, None, None
+    traffic, traffic_from, sq, ta = None, None, None, None
     tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tfile):
         try:
@@ -412,6 +412,7 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
                         traffic = tj.get("hbm_bytes_per_launch")
                         traffic_from = {"commit": tdoc.get("commit"), "efSearch": ef, "profile": tj.get("profile", tdoc.get("profile"))}
                         sq = tj.get("sq")
+                        ta = tj.get("ta")
                     else:
                         traffic_from = {"stale": "kernels changed since commit %s; rerun scripts/profile.sh" % tdoc.get("commit")}
         except (OSError, ValueError, AttributeError):
@@ -447,6 +448,20 @@ def analyse(c, index, kind_name, tag, ef, recall_by_ef, local_search, kern_ms):
                           "wave_cycles_x4": round(wc / B, 1)},
             "note": "valu_issue_frac = SQ_INSTS_VALU x 4 clocks / (SIMDs x the kernel's clocks) with one wave per SIMD; "
                     "counters from the profile named in traffic_measured_at"}
+    if ta and ta.get("GRBM_GUI_ACTIVE") and ta.get("TA_TA_BUSY_sum"):
+        # ... and the CU's L1 path (scripts/pmc_ta.sh): a lane reads its row 16 bytes at a time, one L1 tag access per
+        # piece; neither the texture addresser nor the tag rate is a roof here -- the path is a third used
+        cyc = float(ta["GRBM_GUI_ACTIVE"]) / 8.0  # (summed over the 8 XCDs)
+        per_cu = lambda k: float(ta.get(k, 0.0)) / 256.0 / cyc
+        out["roofline"]["l1_path"] = {
+            "ta_busy_frac": round(per_cu("TA_TA_BUSY_sum"), 4),
+            "tag_access_frac_of_one_per_clock": round(per_cu("TCP_TOTAL_CACHE_ACCESSES_sum"), 4),
+            "waiting_for_l2_data_frac": round(per_cu("TCP_PENDING_STALL_CYCLES_sum"), 4),
+            "ta_stalled_by_l1_frac": round(per_cu("TA_ADDR_STALLED_BY_TC_CYCLES_sum"), 4),
+            "per_query": {"l1_tag_accesses": round(float(ta.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0)) / B, 1),
+                          "l2_read_requests": round(float(ta.get("TCP_TCC_READ_REQ_sum", 0.0)) / B, 1)},
+            "note": "TA / TCP counters summed over 256 CUs / (256 x the kernel's clocks); counters from the profile named in "
+                    "traffic_measured_at (profiles/r04_ta_tcp_counters.txt)"}
     out["recall_at_%d" % n] = recall_by_ef[ef]
     out["ground_truth"] = getattr(c, "ground_truth", None)
     out["recall_by_ef"] = {str(k): v for k, v in sorted(recall_by_ef.items())}

@@ -56,6 +56,9 @@ for e in t["entries"]:
     sqf = os.path.join(ROOT, "gpurun_out", "sq_%s_%d" % (kind, e["ef"]), "sq.json")
     if os.path.exists(sqf) and e["workload"].startswith("n1000000_d100_"):
         e["sq"] = json.load(open(sqf))
+    taf = os.path.join(ROOT, "gpurun_out", "ta_%s_%d" % (kind, e["ef"]), "ta.json")  # scripts/pmc_ta.sh KIND EF
+    if os.path.exists(taf) and e["workload"].startswith("n1000000_d100_"):
+        e["ta"] = json.load(open(taf))
 lf = os.path.join(prof, "latency_floor_latest.json")
 if os.path.exists(lf):
     fdoc = json.load(open(lf))

@@ -69,6 +69,12 @@ for nq in (64, 1024):
          "floor_cycles_mean": round(floor_cyc.mean()), "floor_cycles_of_the_slowest_query": round(floor_cyc[np.argmax(tot)]),
          "floor_ms_slowest_query": round(floor_cyc[np.argmax(tot)] / ghz / 1e6, 4), "floor_ms_mean_query": round(floor_cyc.mean() / ghz / 1e6, 4),
          "floor_over_kernel": round(floor_cyc[np.argmax(tot)] / tot.max(), 3)}
+    # the bookkeeping term in its parts (stamps 8, 9, 5, 10), per pass, and how many merges inserted 0 / 1-2 / more keys
+    r["bookkeeping_cycles_per_pass"] = {"merge_of_c": round(D[:, 8].mean() / passes.mean()), "is_p_next_and_prefetch": round(D[:, 9].mean() / passes.mean()),
+                                        "claims_of_p": round(D[:, 5].mean() / passes.mean()), "merge_of_p": round(D[:, 10].mean() / passes.mean())}
+    r["per_query_counts"] = {"p_commits": round(D[:, 15].mean(), 2), "merges_inserting_0": round(D[:, 12].mean(), 2),
+                             "merges_inserting_1_or_2": round(D[:, 13].mean(), 2), "merges_inserting_more": round(D[:, 14].mean(), 2),
+                             "passes_with_a_second_claim_round": round(D[:, 11].mean(), 2)}
     res[str(nq)] = r
     print(json.dumps(r))
 if outp:
