@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "device_index.h"
+#include "shard_exchange.h"
 #include "host_index.h"
 
 using hx::set_error;
@@ -1061,7 +1062,7 @@ void clamp_rows_to_cap(hx::HostIndex &host, std::vector<uint64_t> *restore) {
 // every record, the rank that owns a row (node id % world) appends / prunes / drops in it -- each row's outcome
 // depends on that row and its records alone, so the split changes nothing -- the removals phase 2 files are
 // all-gathered between the two phases, and the rows an owner changed travel to the other replicas as whole rows of
-// ids at the end of the batch (hx_pack_rows_kernel / hx_apply_rows_kernel).  Four collectives per batch (records;
+// ids at the end of the batch (hx_pack_rows_kernel / hx_apply_rows_kernel).  Five collectives per batch (records;
 // removal counts + removals; row counts + rows -- the count exchanges are 64 B per rank and carry the rank's status,
 // so the ranks stop together), the replicas identical after each.  HNSW_MI355X_SHARD_CONNECT=0: phases 2 / 3 on
 // every rank in full, as before round 4 (one collective per batch).
@@ -1351,7 +1352,7 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         a.adjd0_mut = adjd0;
         a.adjd_up_mut = adjd_up;
         a.counters = dRead.as<unsigned long long>();
-        uint32_t nreq = 0;
+        uint32_t nreq = 0, nreq_all = 0;  // records this rank sorts and applies; records of the batch
         auto timed_insert = [&](uint32_t nblocks, int adjust) -> int {
             HIP_TRY(hipEventRecord(ev.a, nullptr));
             const int r = hx::launch_insert(v, a, nblocks, nullptr, adjust);
@@ -1405,6 +1406,7 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
                 set_error("on-device build: record counter %u beyond the capacity %u", nreq, REQ_CAP);
                 return HNSW_ERR_OVERFLOW;
             }
+            nreq_all = nreq;
         } else {
             // the slot: [count, nfail, ...64 B][failed ids][keys][vals]
             unsigned char *slot = sh->d_send;
@@ -1477,7 +1479,13 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
                     HIP_TRY(hipMemcpy(f.data(), rs + SH_HEADER, rh[1] * 4, hipMemcpyDeviceToHost));
                     failed.insert(failed.end(), f.begin(), f.end());
                 }
-                if (rh[0]) {
+                if (rh[0] && own_rows) {
+                    // this rank's share of the slot's records: the rows it owns (the others' never reach its sort)
+                    rc = hx::filter_edge_records(reinterpret_cast<const uint64_t *>(rs + o_keys), reinterpret_cast<const uint32_t *>(rs + o_vals),
+                                                 rh[0], sh->rank, W, dKeyA.as<uint64_t>(), dValA.as<uint32_t>(), cnt + 0, REQ_CAP,
+                                                 reinterpret_cast<int32_t *>(cnt + 3), nullptr);
+                    if (rc != HNSW_OK) return rc;
+                } else if (rh[0]) {
                     HIP_TRY(hipMemcpyAsync(dKeyA.as<uint64_t>() + nreq, rs + o_keys, (size_t)rh[0] * 8,
                                            hipMemcpyDeviceToDevice, nullptr));
                     HIP_TRY(hipMemcpyAsync(dValA.as<uint32_t>() + nreq, rs + o_vals, (size_t)rh[0] * 4,
@@ -1485,6 +1493,8 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
                 }
                 nreq += rh[0];
             }
+            nreq_all = nreq;
+            if (own_rows) HIP_TRY(hipMemcpy(&nreq, cnt + 0, 4, hipMemcpyDeviceToHost));  // (the counter was zeroed with the batch)
         }
         auto t1 = std::chrono::steady_clock::now();
         // ---- phase 2: group by target row (radix sort), append / prune ----
@@ -1525,7 +1535,7 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
             set_error("on-device build: connect kernel reported status %d in batch %zu", (int)counts[3], n_batches);
             return (int)counts[3];
         }
-        uint32_t nrem = counts[1];
+        uint32_t nrem = counts[1], nrem_all = counts[1];
         if (own_rows) {
             // the removals of every owner's prunes, in every rank's list (phase 3 filters by the owner of the row
             // that loses the edge); the sort below makes the order canonical
@@ -1538,13 +1548,17 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
                 set_error("sharded build: %llu removals in one batch, room for %u", (unsigned long long)tot, REQ_CAP);
                 return HNSW_ERR_OVERFLOW;
             }
-            nrem = 0;
+            // ... of which this rank sorts and applies those that drop from a row it owns
+            HIP_TRY(hipMemset(cnt + 1, 0, 4));
             for (uint32_t r = 0; r < W; r++) {
-                if (x_counts[r])
-                    HIP_TRY(hipMemcpyAsync(dKeyA.as<uint64_t>() + nrem, sh->d_recv + (size_t)r * x_stride + SH_HEADER,
-                                           (size_t)x_counts[r] * 8, hipMemcpyDeviceToDevice, nullptr));
-                nrem += x_counts[r];
+                if (x_counts[r] == 0) continue;
+                rc = hx::filter_edge_records(reinterpret_cast<const uint64_t *>(sh->d_recv + (size_t)r * x_stride + SH_HEADER), nullptr,
+                                             x_counts[r], sh->rank, W, dKeyA.as<uint64_t>(), nullptr, cnt + 1, REQ_CAP,
+                                             reinterpret_cast<int32_t *>(cnt + 3), nullptr);
+                if (rc != HNSW_OK) return rc;
             }
+            nrem_all = (uint32_t)tot;
+            HIP_TRY(hipMemcpy(&nrem, cnt + 1, 4, hipMemcpyDeviceToHost));
         }
         // ---- phase 3: group the removals by row, drop the reverse edges ----
         rc = hx::sort_edge_keys(dTemp.p, temp_bytes, dKeyA.as<uint64_t>(), dKeyB.as<uint64_t>(), nrem, L, nullptr);
@@ -1597,8 +1611,8 @@ int gpu_insert_bulk_full(hnsw_index *h, const float *rows, uint64_t n, uint32_t 
         auto t2 = std::chrono::steady_clock::now();
         t_ins += std::chrono::duration<double>(t1 - t0).count();
         t_conn += std::chrono::duration<double>(t2 - t1).count();
-        n_req += nreq;
-        n_rem += nrem;
+        n_req += nreq_all;
+        n_rem += nrem_all;
         pos += B;
         connected += B;
         n_batches++;

@@ -11,8 +11,15 @@ thr = min(32, os.cpu_count())
 vs = H.synth_rows(recipe, 0x5EED0001, 0, N, d, thr); qs = H.synth_rows(recipe, 0x5EED0002, 0, 1024, d, 8)
 mode = int(os.environ.get('MODE', '2'))
 dev = H.HNSW.new(m, 32, d, kind); dev.set_option('gpu_build', mode)
+if os.environ.get('BATCH'):  # "max:div", e.g. 32768:8 (bench.py --config 4)
+    bmax, bdiv = (int(x) for x in os.environ['BATCH'].split(':'))
+    dev.set_option('gpu_build_batch_max', bmax); dev.set_option('gpu_build_batch_div', bdiv)
 t = time.time(); dev.insert_bulk_device(vs, thr, True); t_dev = time.time() - t
 print('device build %.1fs layers=%d compliant=%s' % (t_dev, dev.nb_layers(), dev.assert_param_compliance()), flush=True)
+g = lambda k: dev.stat('build_' + k) / 1e6
+print('build clocks: insert kernel %.2f s (HIP events), insert phase %.2f s, sort + connect + remove phase %.2f s of which the '
+      'connect + drop kernels %.2f s (HIP events); batch max %s' % (g('insert_kernel_us'), g('insert_phase_us'), g('connect_us'),
+                                                                    g('connect_kernel_us'), os.environ.get('BATCH', 'default')), flush=True)
 truth, _ = dev.brute_force(qs, 10)
 for ef in (64, 96, 256):
     ids, _, _, st = dev.search_batch(qs, 10, ef)
