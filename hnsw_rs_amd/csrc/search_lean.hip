@@ -1462,6 +1462,8 @@ __global__ void __launch_bounds__(64) hx_lean_q8_kernel(const LeanArgs a) {
     }
 }
 
+#include "pair_kernel.inc"
+
 template <class LT>
 int launch_lean_q8(const LeanArgs &a_in, uint32_t nblocks, hipStream_t stream) {
     constexpr int R = LT::NR;
@@ -1637,6 +1639,13 @@ int launch_lean(const DevView &v, const SearchArgs &s, uint32_t nblocks, uint32_
         if (a.ef > 256) return launch_lean_one<128, Lst<6>, 2>(a, nblocks, stream);
         if (a.ef > 128) return launch_lean_one<128, Lst<4>, 2>(a, nblocks, stream);
         return few ? launch_lean_one<128, LstHT, 4>(a, nblocks, stream) : launch_lean_one<128, LstHT, 2>(a, nblocks, stream);
+    }
+    // two waves per query (pair_kernel.inc): launches that leave the SIMDs a wave or two each
+    static const int pair_mode = getenv("HNSW_MI355X_PAIR") ? atoi(getenv("HNSW_MI355X_PAIR")) : 0;
+    // (a.qsel: a re-run of the queries a first launch gave up -- those take the one-wave kernel)
+    if (pair_mode != 0 && a.ef <= 128 && !interleaved && a.qsel == nullptr) {
+        if (a.ef <= 64) return launch_pair<100, Lst<1>>(a, nblocks, stream);
+        return launch_pair<100, LstHT>(a, nblocks, stream);
     }
     if (a.ef <= 64) return launch_lean_one<100, Lst<1>>(a, nblocks, stream);
     // 256 < ef <= 512: as many interleaved registers as the list needs (round 4: five to eight; every register costs

@@ -34,6 +34,13 @@ def test_lean_kernels_fit_two_waves_per_simd_without_agprs_or_scratch(tmp_path):
     # f32 100d and quant8: one register, head + tail, interleaved two (A/B), interleaved four (ef 129..256); f32 128d
     # (cooperative gather): one register and head + tail at two stage depths each, interleaved four
     assert len(timed) == 23, sorted(kernels)  # (+ five to eight interleaved registers for ef 257..512: f32 100d, quant8; six / eight for f32 128d)
+    # the two-wave form (pair_kernel.inc, opt-in): one register and head + tail; a workgroup is two waves, four
+    # workgroups per CU by LDS, so it must stay within 256 registers without scratch
+    pair = {k: v for k, v in kernels.items() if "hx_pair_f32_kernel" in k}
+    assert len(pair) == 2, sorted(kernels)
+    for name, r in pair.items():
+        assert r.get("ScratchSize", 0) == 0 and r.get("VGPRs Spill", 0) == 0 and r.get("AGPRs", 0) == 0, (name, r)
+        assert r.get("VGPRs", 999) <= 256, (name, r)
     for name, r in timed.items():
         assert r.get("ScratchSize", 0) == 0 and r.get("VGPRs Spill", 0) == 0, (name, r)
         if "ILi128E" in name or ("hx_lean_f32_kernel" in name and re.search(r"LstILi[5678]E", name)):
